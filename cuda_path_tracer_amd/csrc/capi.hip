@@ -1,0 +1,506 @@
+// Implementation of the C ABI declared in include/cpt_amd.h: context, scene upload, the render
+// loop of the wavefront pipeline, and the parity hooks.  Host code only; the kernels live in
+// kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cpt_amd.h"
+#include "launch.h"
+
+#define CPT_STACK_ENTRIES_HOST 32  // must equal CPT_STACK_ENTRIES in device_core.h
+#define CPT_MAX_DEPTH 1022
+
+static_assert(sizeof(cpt_node) == 128, "cpt_node must be 128 bytes");
+static_assert(sizeof(cpt_tri) == 128, "cpt_tri must be 128 bytes");
+static_assert(sizeof(cpt_tri_normals) == 72, "cpt_tri_normals must be 72 bytes");
+static_assert(sizeof(cpt_material) == 136, "cpt_material must be 136 bytes");
+
+struct cpt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+
+    void *d_nodes = nullptr, *d_tris = nullptr, *d_tnorm = nullptr, *d_mats = nullptr;
+    DScene sc{};
+    bool has_scene = false;
+    int n_tree_nodes = 0, tree_height = 0;
+
+    void* d_paths = nullptr;
+    size_t path_capacity = 0;
+    PathArrays A{};
+    uint32_t* d_queue[2] = {nullptr, nullptr};
+    uint32_t* d_counters = nullptr;        // CPT_MAX_DEPTH + 2 queue lengths
+    unsigned long long* d_work = nullptr;  // paths, segments, hits, node steps, triangle tests
+
+    bool time_kernels = false, count_work = false;
+    cpt_stats stats{};
+    std::vector<hipEvent_t> events;
+
+    int max_blocks = 0;            // grid cap of the grid-stride kernels
+    long long batch_paths = 1 << 21;  // path slots kept in flight by the wavefront pipeline
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(cpt_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+#define HIP_TRY(c, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return fail((c), CPT_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static void free_scene(cpt_ctx* c) {
+    if (c->d_nodes) (void)hipFree(c->d_nodes);
+    if (c->d_tris) (void)hipFree(c->d_tris);
+    if (c->d_tnorm) (void)hipFree(c->d_tnorm);
+    if (c->d_mats) (void)hipFree(c->d_mats);
+    c->d_nodes = c->d_tris = c->d_tnorm = c->d_mats = nullptr;
+    c->has_scene = false;
+}
+static void free_paths(cpt_ctx* c) {
+    if (c->d_paths) (void)hipFree(c->d_paths);
+    if (c->d_queue[0]) (void)hipFree(c->d_queue[0]);
+    if (c->d_queue[1]) (void)hipFree(c->d_queue[1]);
+    c->d_paths = nullptr;
+    c->d_queue[0] = c->d_queue[1] = nullptr;
+    c->path_capacity = 0;
+}
+
+extern "C" {
+
+int cpt_create(int device, cpt_ctx** out) {
+    if (!out) return fail(nullptr, CPT_EINVAL, "cpt_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(nullptr, hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(nullptr, CPT_EINVAL, "cpt_create: device %d not in [0, %d)", device, n);
+    HIP_TRY(nullptr, hipSetDevice(device));
+    cpt_ctx* c = new cpt_ctx;
+    c->device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { delete c; return fail(nullptr, CPT_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
+    c->max_blocks = prop.multiProcessorCount * 8;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(nullptr, CPT_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    c->stream = c->own_stream;
+    e = hipMalloc((void**)&c->d_counters, (CPT_MAX_DEPTH + 2) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_work, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(c->d_work, 0, 8 * sizeof(unsigned long long));
+    if (e != hipSuccess) { cpt_destroy(c); return fail(nullptr, CPT_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    *out = c;
+    return CPT_OK;
+}
+
+void cpt_destroy(cpt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    free_paths(c);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_work) (void)hipFree(c->d_work);
+    for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* cpt_last_error(const cpt_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int cpt_set_stream(cpt_ctx* c, void* s) {
+    if (!c) return CPT_EINVAL;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return CPT_OK;
+}
+
+int cpt_set_instrumentation(cpt_ctx* c, int time_kernels, int count_work) {
+    if (!c) return CPT_EINVAL;
+    c->time_kernels = time_kernels != 0;
+    c->count_work = count_work != 0;
+    return CPT_OK;
+}
+
+int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
+    if (!c || !key) return CPT_EINVAL;
+    if (!strcmp(key, "batch_paths")) {
+        if (value < 64) return fail(c, CPT_EINVAL, "batch_paths must be >= 64");
+        c->batch_paths = value;
+    } else if (!strcmp(key, "max_blocks")) {
+        if (value < 1) return fail(c, CPT_EINVAL, "max_blocks must be >= 1");
+        c->max_blocks = (int)value;
+    } else {
+        return fail(c, CPT_EINVAL, "unknown option '%s'", key);
+    }
+    return CPT_OK;
+}
+
+// Structural validation of the flattened scene: every kernel indexes these arrays without bounds
+// checks, so a malformed scene must be refused here.
+static int validate_scene(cpt_ctx* c, const cpt_scene_desc* s) {
+    if (s->n_tris < 1) return fail(c, CPT_EINVAL, "scene has no triangles");
+    if (s->n_materials < 1) return fail(c, CPT_EINVAL, "scene has no materials");
+    if (!s->tris || !s->tri_normals || !s->materials) return fail(c, CPT_EINVAL, "scene arrays missing");
+    if (s->n_nodes != s->n_tris - 1) return fail(c, CPT_EINVAL, "n_nodes (%d) != n_tris - 1 (%d)", s->n_nodes, s->n_tris - 1);
+    if (s->n_nodes > 0 && !s->nodes) return fail(c, CPT_EINVAL, "nodes missing");
+    if (s->n_tree_nodes != 2 * s->n_tris - 1) return fail(c, CPT_EINVAL, "n_tree_nodes must be 2*n_tris-1");
+    if (s->tree_height - 2 > CPT_STACK_ENTRIES_HOST)
+        return fail(c, CPT_ELIMIT, "tree height %d needs a %d-entry stack; limit is %d", s->tree_height, s->tree_height - 2, CPT_STACK_ENTRIES_HOST);
+    for (int i = 0; i < s->n_tris; ++i)
+        if (s->tris[i].material < 0 || s->tris[i].material >= s->n_materials) return fail(c, CPT_EINVAL, "triangle %d: bad material", i);
+    std::vector<unsigned char> seen_tri((size_t)s->n_tris, 0), seen_node((size_t)std::max(s->n_nodes, 1), 0);
+    for (int k = 0; k < s->n_nodes; ++k) {
+        const int refs[2] = {s->nodes[k].lref, s->nodes[k].rref};
+        const int ids[2] = {s->nodes[k].lid, s->nodes[k].rid};
+        for (int q = 0; q < 2; ++q) {
+            if (ids[q] < 0 || ids[q] >= s->n_tree_nodes) return fail(c, CPT_EINVAL, "node %d: canonical id out of range", k);
+            if (refs[q] >= 0) {
+                if (refs[q] <= k || refs[q] >= s->n_nodes) return fail(c, CPT_EINVAL, "node %d: child record %d not after its parent", k, refs[q]);
+                if (seen_node[refs[q]]++) return fail(c, CPT_EINVAL, "node record %d has two parents", refs[q]);
+            } else {
+                int t = ~refs[q];
+                if (t < 0 || t >= s->n_tris) return fail(c, CPT_EINVAL, "node %d: leaf triangle out of range", k);
+                if (seen_tri[t]++) return fail(c, CPT_EINVAL, "triangle %d is in two leaves", t);
+            }
+        }
+    }
+    return CPT_OK;
+}
+
+int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
+    if (!c || !s) return CPT_EINVAL;
+    int rc = validate_scene(c, s);
+    if (rc != CPT_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    size_t nb = sizeof(cpt_node) * (size_t)std::max(s->n_nodes, 1);
+    HIP_TRY(c, hipMalloc(&c->d_nodes, nb));
+    HIP_TRY(c, hipMalloc(&c->d_tris, sizeof(cpt_tri) * (size_t)s->n_tris));
+    HIP_TRY(c, hipMalloc(&c->d_tnorm, sizeof(cpt_tri_normals) * (size_t)s->n_tris));
+    HIP_TRY(c, hipMalloc(&c->d_mats, sizeof(cpt_material) * (size_t)s->n_materials));
+    if (s->n_nodes > 0) HIP_TRY(c, hipMemcpy(c->d_nodes, s->nodes, sizeof(cpt_node) * (size_t)s->n_nodes, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tris, s->tris, sizeof(cpt_tri) * (size_t)s->n_tris, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tnorm, s->tri_normals, sizeof(cpt_tri_normals) * (size_t)s->n_tris, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_mats, s->materials, sizeof(cpt_material) * (size_t)s->n_materials, hipMemcpyHostToDevice));
+    c->sc.nodes = (const cpt_node*)c->d_nodes;
+    c->sc.tris = (const cpt_tri*)c->d_tris;
+    c->sc.tnorm = (const cpt_tri_normals*)c->d_tnorm;
+    c->sc.mats = (const cpt_material*)c->d_mats;
+    c->sc.cam = s->camera;
+    c->sc.n_nodes = s->n_nodes;
+    c->sc.n_tris = s->n_tris;
+    c->n_tree_nodes = s->n_tree_nodes;
+    c->tree_height = s->tree_height;
+    c->has_scene = true;
+    return CPT_OK;
+}
+
+static int ensure_paths(cpt_ctx* c, size_t slots) {
+    if (slots <= c->path_capacity) return CPT_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_paths(c);
+    HIP_TRY(c, hipMalloc(&c->d_paths, slots * CPT_PATH_BYTES));
+    HIP_TRY(c, hipMalloc((void**)&c->d_queue[0], slots * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_queue[1], slots * sizeof(uint32_t)));
+    double* base = (double*)c->d_paths;
+    double** fields[CPT_PATH_DOUBLES] = {&c->A.ox, &c->A.oy, &c->A.oz, &c->A.dx, &c->A.dy, &c->A.dz, &c->A.medium,
+                                         &c->A.ax, &c->A.ay, &c->A.az, &c->A.cx, &c->A.cy, &c->A.cz, &c->A.hit_t};
+    for (int f = 0; f < CPT_PATH_DOUBLES; ++f) *fields[f] = base + (size_t)f * slots;
+    c->A.hit_tri = (int*)(base + (size_t)CPT_PATH_DOUBLES * slots);
+    c->path_capacity = slots;
+    return CPT_OK;
+}
+
+static int make_params(cpt_ctx* c, const cpt_render_params* p, DParams& P) {
+    if (p->width < 1 || p->height < 1) return fail(c, CPT_EINVAL, "bad image size %dx%d", p->width, p->height);
+    if ((long long)p->width * p->height > (1ll << 28)) return fail(c, CPT_ELIMIT, "image too large");
+    if (p->sample_begin < 0 || p->sample_end < p->sample_begin) return fail(c, CPT_EINVAL, "bad sample range [%d, %d)", p->sample_begin, p->sample_end);
+    if (p->depth < 0 || p->depth > CPT_MAX_DEPTH) return fail(c, CPT_EINVAL, "depth %d not in [0, %d]", p->depth, CPT_MAX_DEPTH);
+    if (p->mode != CPT_MODE_WAVEFRONT && p->mode != CPT_MODE_MEGAKERNEL) return fail(c, CPT_EINVAL, "unknown mode %d", p->mode);
+    P.w = p->width; P.h = p->height; P.s0 = p->sample_begin; P.s1 = p->sample_end; P.depth = p->depth;
+    P.dof = p->dof ? 1 : 0; P.rr = p->russian_roulette ? 1 : 0;
+    P.seed_lo = (uint32_t)p->seed; P.seed_hi = (uint32_t)(p->seed >> 32);
+    P.focal_distance = p->focal_distance; P.aperture = p->aperture;
+    P.tiles_x = (p->width + 7) / 8; P.tiles_y = (p->height + 7) / 8;
+    P.n_pix_slots = P.tiles_x * P.tiles_y * 64;
+    return CPT_OK;
+}
+
+static int need_events(cpt_ctx* c, size_t n) {
+    while (c->events.size() < n) {
+        hipEvent_t ev;
+        HIP_TRY(c, hipEventCreate(&ev));
+        c->events.push_back(ev);
+    }
+    return CPT_OK;
+}
+
+static int collect_work(cpt_ctx* c) {
+    unsigned long long w[8];
+    HIP_TRY(c, hipMemcpyAsync(w, c->d_work, sizeof w, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_work, 0, sizeof w, c->stream));
+    c->stats.segments += w[1];
+    c->stats.hits += w[2];
+    c->stats.node_steps += w[3];
+    c->stats.tri_tests += w[4];
+    return CPT_OK;
+}
+
+int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
+    if (!c || !p || !d_accum) return c ? fail(c, CPT_EINVAL, "cpt_render: NULL argument") : CPT_EINVAL;
+    if (!c->has_scene) return fail(c, CPT_ENOSCENE, "cpt_render: no scene uploaded");
+    DParams P;
+    int rc = make_params(c, p, P);
+    if (rc != CPT_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (P.s1 == P.s0) return CPT_OK;
+    LaunchCfg L{c->stream, c->max_blocks};
+    unsigned long long* work = c->count_work ? c->d_work : nullptr;
+    const bool timed = c->time_kernels;
+    long long n_paths = (long long)P.w * P.h * (P.s1 - P.s0);
+
+    if (p->mode == CPT_MODE_MEGAKERNEL) {
+        if (timed) { rc = need_events(c, 2); if (rc) return rc; HIP_TRY(c, hipEventRecord(c->events[0], c->stream)); }
+        launch_megakernel(L, c->sc, P, d_accum, work);
+        HIP_TRY(c, hipGetLastError());
+        if (timed) {
+            HIP_TRY(c, hipEventRecord(c->events[1], c->stream));
+            HIP_TRY(c, hipEventSynchronize(c->events[1]));
+            float ms = 0;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->events[0], c->events[1]));
+            c->stats.ms_mega += ms;
+            c->stats.ms_total += ms;
+        }
+        c->stats.launches_mega++;
+        c->stats.paths += (uint64_t)n_paths;
+        if (work) return collect_work(c);
+        return CPT_OK;
+    }
+
+    // wavefront: batches of whole samples
+    long long per_sample = P.n_pix_slots;
+    int batch = (int)std::max(1ll, std::min((long long)(P.s1 - P.s0), c->batch_paths / per_sample));
+    rc = ensure_paths(c, (size_t)batch * (size_t)per_sample);
+    if (rc) return rc;
+    const size_t n_ev = 2 * (size_t)(P.depth + 1) + 3;
+    if (timed) { rc = need_events(c, n_ev); if (rc) return rc; }
+    for (int bs = P.s0; bs < P.s1; bs += batch) {
+        int bn = std::min(batch, P.s1 - bs);
+        long long slots = (long long)bn * per_sample;
+        size_t ev = 0;
+        HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, (size_t)(P.depth + 2) * sizeof(uint32_t), c->stream));
+        if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
+        launch_generate(L, c->sc, P, c->A, bs, bn, c->d_queue[0], c->d_counters);
+        if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
+        for (int b = 0; b <= P.depth; ++b) {
+            launch_extend(L, c->sc, c->A, c->d_queue[b & 1], c->d_counters + b, slots, work);
+            if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
+            launch_shade(L, c->sc, P, c->A, bs, b, c->d_queue[b & 1], c->d_counters + b, c->d_queue[(b + 1) & 1],
+                         c->d_counters + b + 1, slots, work);
+            if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
+        }
+        launch_resolve(L, P, c->A, bn, d_accum);
+        HIP_TRY(c, hipGetLastError());
+        c->stats.launches_generate++;
+        c->stats.launches_extend += (uint64_t)(P.depth + 1);
+        c->stats.launches_shade += (uint64_t)(P.depth + 1);
+        c->stats.iterations += (uint64_t)(P.depth + 1);
+        if (timed) {
+            HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
+            HIP_TRY(c, hipEventSynchronize(c->events[ev - 1]));
+            float ms = 0;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->events[0], c->events[1]));
+            c->stats.ms_generate += ms;
+            for (int b = 0; b <= P.depth; ++b) {
+                HIP_TRY(c, hipEventElapsedTime(&ms, c->events[1 + 2 * b], c->events[2 + 2 * b]));
+                c->stats.ms_extend += ms;
+                HIP_TRY(c, hipEventElapsedTime(&ms, c->events[2 + 2 * b], c->events[3 + 2 * b]));
+                c->stats.ms_shade += ms;
+            }
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->events[0], c->events[ev - 1]));
+            c->stats.ms_total += ms;
+        }
+    }
+    c->stats.paths += (uint64_t)n_paths;
+    if (work) return collect_work(c);
+    return CPT_OK;
+}
+
+int cpt_tonemap(cpt_ctx* c, const double* d_accum, int32_t w, int32_t h, int32_t total_spp, uint8_t* d_rgb) {
+    if (!c || !d_accum || !d_rgb) return c ? fail(c, CPT_EINVAL, "cpt_tonemap: NULL argument") : CPT_EINVAL;
+    if (w < 1 || h < 1 || total_spp < 1) return fail(c, CPT_EINVAL, "cpt_tonemap: bad size or sample count");
+    HIP_TRY(c, hipSetDevice(c->device));
+    LaunchCfg L{c->stream, c->max_blocks};
+    launch_tonemap(L, d_accum, w * h * 3, total_spp, d_rgb);
+    HIP_TRY(c, hipGetLastError());
+    return CPT_OK;
+}
+
+int cpt_render_image(cpt_ctx* c, const cpt_render_params* p, uint8_t* h_rgb) {
+    if (!c || !p || !h_rgb) return c ? fail(c, CPT_EINVAL, "cpt_render_image: NULL argument") : CPT_EINVAL;
+    if (p->sample_end <= p->sample_begin) return fail(c, CPT_EINVAL, "cpt_render_image: empty sample range");
+    if (p->width < 1 || p->height < 1) return fail(c, CPT_EINVAL, "bad image size");
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t n = (size_t)p->width * p->height * 3;
+    double* d_accum = nullptr;
+    uint8_t* d_rgb = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_accum, n * sizeof(double)));
+    hipError_t e = hipMalloc((void**)&d_rgb, n);
+    if (e != hipSuccess) { (void)hipFree(d_accum); return fail(c, CPT_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    int rc = CPT_OK;
+    e = hipMemsetAsync(d_accum, 0, n * sizeof(double), c->stream);
+    if (e != hipSuccess) rc = fail(c, CPT_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+    if (rc == CPT_OK) rc = cpt_render(c, p, d_accum);
+    if (rc == CPT_OK) rc = cpt_tonemap(c, d_accum, p->width, p->height, p->sample_end - p->sample_begin, d_rgb);
+    if (rc == CPT_OK) {
+        e = hipMemcpyAsync(h_rgb, d_rgb, n, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, CPT_EHIP, "copy back: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_accum);
+    (void)hipFree(d_rgb);
+    return rc;
+}
+
+int cpt_synchronize(cpt_ctx* c) {
+    if (!c) return CPT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CPT_OK;
+}
+
+int cpt_get_stats(cpt_ctx* c, cpt_stats* out) {
+    if (!c || !out) return CPT_EINVAL;
+    *out = c->stats;
+    return CPT_OK;
+}
+int cpt_reset_stats(cpt_ctx* c) {
+    if (!c) return CPT_EINVAL;
+    c->stats = cpt_stats{};
+    return CPT_OK;
+}
+
+// ---- parity hooks: small scratch buffers, blocking ---------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+
+int cpt_trace_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, int32_t* h_tri, double* h_t,
+                   double* h_normal, uint64_t* h_vhash, int32_t* h_counts, uint8_t* h_bitmap, int32_t stride) {
+    if (!c || !h_o || !h_d || !h_tri || !h_t || n < 0) return c ? fail(c, CPT_EINVAL, "cpt_trace_rays: bad argument") : CPT_EINVAL;
+    if (!c->has_scene) return fail(c, CPT_ENOSCENE, "cpt_trace_rays: no scene uploaded");
+    if (h_bitmap && stride * 8 < c->n_tree_nodes) return fail(c, CPT_EINVAL, "bitmap_stride %d too small for %d nodes", stride, c->n_tree_nodes);
+    if (n == 0) return CPT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf o, d, tri, t, nrm, vh, cnt, bm;
+    size_t N = (size_t)n;
+    HIP_TRY(c, o.alloc(N * 24)); HIP_TRY(c, d.alloc(N * 24)); HIP_TRY(c, tri.alloc(N * 4)); HIP_TRY(c, t.alloc(N * 8));
+    HIP_TRY(c, nrm.alloc(N * 24)); HIP_TRY(c, vh.alloc(N * 8)); HIP_TRY(c, cnt.alloc(N * 16));
+    if (h_bitmap) { HIP_TRY(c, bm.alloc(N * (size_t)stride)); HIP_TRY(c, hipMemsetAsync(bm.p, 0, N * (size_t)stride, c->stream)); }
+    HIP_TRY(c, hipMemcpyAsync(o.p, h_o, N * 24, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d.p, h_d, N * 24, hipMemcpyHostToDevice, c->stream));
+    LaunchCfg L{c->stream, c->max_blocks};
+    launch_trace_rays(L, c->sc, n, (const double*)o.p, (const double*)d.p, (int*)tri.p, (double*)t.p, (double*)nrm.p,
+                      (unsigned long long*)vh.p, (int*)cnt.p, h_bitmap ? (uint8_t*)bm.p : nullptr, stride);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(h_tri, tri.p, N * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_t, t.p, N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (h_normal) HIP_TRY(c, hipMemcpyAsync(h_normal, nrm.p, N * 24, hipMemcpyDeviceToHost, c->stream));
+    if (h_vhash) HIP_TRY(c, hipMemcpyAsync(h_vhash, vh.p, N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (h_counts) HIP_TRY(c, hipMemcpyAsync(h_counts, cnt.p, N * 16, hipMemcpyDeviceToHost, c->stream));
+    if (h_bitmap) HIP_TRY(c, hipMemcpyAsync(h_bitmap, bm.p, N * (size_t)stride, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CPT_OK;
+}
+
+int cpt_camera_rays(cpt_ctx* c, int32_t w, int32_t h, double jx, double jy, double* h_o, double* h_d) {
+    if (!c || !h_o || !h_d || w < 1 || h < 1) return c ? fail(c, CPT_EINVAL, "cpt_camera_rays: bad argument") : CPT_EINVAL;
+    if (!c->has_scene) return fail(c, CPT_ENOSCENE, "cpt_camera_rays: no scene uploaded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t N = (size_t)w * h;
+    DevBuf o, d;
+    HIP_TRY(c, o.alloc(N * 24)); HIP_TRY(c, d.alloc(N * 24));
+    LaunchCfg L{c->stream, c->max_blocks};
+    launch_camera_rays(L, c->sc, w, h, jx, jy, (double*)o.p, (double*)d.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(h_o, o.p, N * 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_d, d.p, N * 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CPT_OK;
+}
+
+int cpt_path_radiance(cpt_ctx* c, const cpt_render_params* p, int32_t n, const int32_t* h_ijs, double* h_rad) {
+    if (!c || !p || !h_ijs || !h_rad || n < 0) return c ? fail(c, CPT_EINVAL, "cpt_path_radiance: bad argument") : CPT_EINVAL;
+    if (!c->has_scene) return fail(c, CPT_ENOSCENE, "cpt_path_radiance: no scene uploaded");
+    DParams P;
+    int rc = make_params(c, p, P);
+    if (rc) return rc;
+    for (int k = 0; k < n; ++k)
+        if (h_ijs[3 * k] < 0 || h_ijs[3 * k] >= P.w || h_ijs[3 * k + 1] < 0 || h_ijs[3 * k + 1] >= P.h || h_ijs[3 * k + 2] < 0)
+            return fail(c, CPT_EINVAL, "path %d: pixel or sample out of range", k);
+    if (n == 0) return CPT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf ij, rad;
+    size_t N = (size_t)n;
+    HIP_TRY(c, ij.alloc(N * 12)); HIP_TRY(c, rad.alloc(N * 24));
+    HIP_TRY(c, hipMemcpyAsync(ij.p, h_ijs, N * 12, hipMemcpyHostToDevice, c->stream));
+    LaunchCfg L{c->stream, c->max_blocks};
+    launch_path_radiance(L, c->sc, P, n, (const int*)ij.p, (double*)rad.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(h_rad, rad.p, N * 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CPT_OK;
+}
+
+int cpt_probe_math(cpt_ctx* c, int32_t n, const double* h_a, const double* h_b, double* h_sqrt, double* h_div) {
+    if (!c || !h_a || !h_sqrt || !h_div || n < 0) return c ? fail(c, CPT_EINVAL, "cpt_probe_math: bad argument") : CPT_EINVAL;
+    if (n == 0) return CPT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t N = (size_t)n;
+    DevBuf a, b, s, q;
+    HIP_TRY(c, a.alloc(N * 8)); HIP_TRY(c, b.alloc(N * 8)); HIP_TRY(c, s.alloc(N * 8)); HIP_TRY(c, q.alloc(N * 8));
+    HIP_TRY(c, hipMemcpyAsync(a.p, h_a, N * 8, hipMemcpyHostToDevice, c->stream));
+    if (h_b) HIP_TRY(c, hipMemcpyAsync(b.p, h_b, N * 8, hipMemcpyHostToDevice, c->stream));
+    LaunchCfg L{c->stream, c->max_blocks};
+    launch_probe_math(L, n, (const double*)a.p, h_b ? (const double*)b.p : nullptr, (double*)s.p, (double*)q.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(h_sqrt, s.p, N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_div, q.p, N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CPT_OK;
+}
+
+int cpt_probe_rng(cpt_ctx* c, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], double out_u[2]) {
+    if (!c || !ctr || !key || !out || !out_u) return c ? fail(c, CPT_EINVAL, "cpt_probe_rng: bad argument") : CPT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf o, u;
+    HIP_TRY(c, o.alloc(16)); HIP_TRY(c, u.alloc(16));
+    LaunchCfg L{c->stream, c->max_blocks};
+    launch_probe_rng(L, ctr, key, (uint32_t*)o.p, (double*)u.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, o.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_u, u.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,384 @@
+// Device-side building blocks of the path tracer for gfx950: slab test, triangle test,
+// stack traversal with the stack in LDS, counter RNG, camera ray, one bounce of shading.
+// Every kernel in kernels.hip is assembled from these, so the wavefront pipeline, the
+// one-thread-per-pixel kernel and the parity hooks compute bit-identical values.
+//
+// All arithmetic is binary64 with contraction off (the translation unit is compiled with
+// -ffp-contract=off); divisions and square roots are the correctly rounded ones.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cpt_amd.h"
+#include "dvec.h"
+#include "launch.h"
+
+#define CPT_WAVE 64
+#define CPT_STACK_ENTRIES 32  // per-lane traversal stack entries held in LDS
+
+// Per-ray observation record filled only by the parity hooks.
+struct TraceRec {
+    uint64_t visit_hash;
+    int node_steps, box_tests, tri_tests, max_stack;
+    uint8_t* bitmap;  // nullable
+};
+
+__device__ __forceinline__ uint64_t visit_mix(uint32_t id) {
+    uint64_t z = (uint64_t)id + 1u;
+    z *= 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Kay-Kajiya slab test with the reference's exact sequence of divisions and comparisons
+// (reference: src/gpu/GPUbb.cuh:16-53, epsilon 1e-12 at :12).  The reference returns from inside
+// the axis loop; a failed axis can never be undone by a later one, so the axes are evaluated
+// without branches and the verdicts are combined.
+__device__ __forceinline__ bool slab_hit(double lx, double ly, double lz, double hx, double hy, double hz,
+                                         const dvec3& o, const dvec3& d) {
+    double tMin = -1.0e308, tMax = 1.0e308;
+    bool ok = true;
+#define CPT_SLAB_AXIS(LO, HI, O, D)                         \
+    {                                                       \
+        double vd = (D);                                    \
+        double t1 = ((LO) - (O)) / vd;                      \
+        double t2 = ((HI) - (O)) / vd;                      \
+        double tn = (t1 > t2) ? t2 : t1;                    \
+        double tf = (t1 > t2) ? t1 : t2;                    \
+        bool live = (vd != 0.0);                            \
+        double nMin = (tn > tMin) ? tn : tMin;              \
+        double nMax = (tf < tMax) ? tf : tMax;              \
+        tMin = live ? nMin : tMin;                          \
+        tMax = live ? nMax : tMax;                          \
+        ok = ok && !(live && ((tMin > tMax) || (tMax < 1e-12))); \
+    }
+    CPT_SLAB_AXIS(lx, hx, o.x, d.x)
+    CPT_SLAB_AXIS(ly, hy, o.y, d.y)
+    CPT_SLAB_AXIS(lz, hz, o.z, d.z)
+#undef CPT_SLAB_AXIS
+    return ok;
+}
+
+// Ray/triangle test (reference: src/gpu/GPUTrimesh.cuh:59-113): plane hit, back-face cull unless
+// the material is reflective/transmissive, t >= 0, three edge tests.  Returns t through t_out.
+__device__ __forceinline__ bool tri_hit(const cpt_tri* __restrict__ tp, const dvec3& o, const dvec3& d,
+                                        double& t_out) {
+    const double2* q = (const double2*)tp;  // 128-byte aligned record: a, b, c, n, material, flags
+    double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+    uint2 mf = ((const uint2*)tp)[12];
+    dvec3 a = dv(q0.x, q0.y, q1.x), b = dv(q1.y, q2.x, q2.y), c = dv(q3.x, q3.y, q4.x), n = dv(q4.y, q5.x, q5.y);
+    bool recur = (mf.y & CPT_TRI_RECUR) != 0;
+    double numerator = -dot(o - a, n);
+    double denominator = dot(d, n);
+    if (denominator >= 0) {
+        if (!recur || denominator == 0) return false;
+    }
+    double t = numerator / denominator;
+    if (t < 0) return false;
+    dvec3 P = o + d * t;
+    dvec3 vba = b - a, vcb = c - b, vac = a - c;
+    dvec3 vpa = P - a, vpb = P - b, vpc = P - c;
+    bool res = dot(cross(vba, vpa), n) >= 0 && dot(cross(vcb, vpb), n) >= 0 && dot(cross(vac, vpc), n) >= 0;
+    t_out = t;
+    return res;
+}
+
+// Closest hit over the scene, visiting exactly the nodes the reference's stack traversal visits
+// (reference: src/gpu/GPUBVH.cu:38-99): both child boxes of every expanded node are tested, leaf
+// children are intersected, the left child is descended and the right one postponed.  There is
+// no near/far ordering and no culling by the current closest hit, so the set of tested nodes is a
+// property of the ray alone.  On equal t the reference keeps the leaf it tested first; its test
+// order is (expansion order of the parent, left before right), and records are stored in
+// expansion order, so the rule is "smaller 2*record + side wins" whatever order we walk in.
+//
+// `stack` points at this lane's column of an LDS array laid out [entry][lane]: entry e of lane l
+// lives at stack[e * CPT_WAVE], which puts the 64 lanes of a wave on distinct banks.
+template <bool TRACE>
+__device__ __forceinline__ void traverse(const DScene& sc, const dvec3& o, const dvec3& d, uint32_t* stack,
+                                         double& best_t, int& best_tri, TraceRec* rec) {
+    best_t = -1.0;
+    best_tri = -1;
+    uint32_t best_rank = 0xFFFFFFFFu;
+    if (sc.n_nodes == 0) {  // one-triangle scene: the reference would dereference a null child
+        if (sc.n_tris > 0) {
+            double t;
+            if (TRACE) rec->tri_tests++;
+            if (tri_hit(sc.tris, o, d, t)) { best_t = t; best_tri = 0; }
+        }
+        return;
+    }
+    int sp = 0;
+    int node = 0;
+    for (;;) {
+        const double2* p = (const double2*)(sc.nodes + node);
+        double2 b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3], b4 = p[4], b5 = p[5];
+        int4 refs = ((const int4*)p)[6];  // lref, rref, lid, rid
+        bool hl = slab_hit(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, o, d);
+        bool hr = slab_hit(b3.x, b3.y, b4.x, b4.y, b5.x, b5.y, o, d);
+        if (TRACE) {
+            rec->node_steps++;
+            rec->box_tests += 2;
+            rec->visit_hash += visit_mix((uint32_t)refs.z) + visit_mix((uint32_t)refs.w);
+            if (rec->bitmap) {
+                rec->bitmap[refs.z >> 3] |= (uint8_t)(1u << (refs.z & 7));
+                rec->bitmap[refs.w >> 3] |= (uint8_t)(1u << (refs.w & 7));
+            }
+        }
+        if (hl && refs.x < 0) {
+            double t;
+            if (TRACE) rec->tri_tests++;
+            if (tri_hit(sc.tris + (~refs.x), o, d, t)) {
+                uint32_t rank = 2u * (uint32_t)node;
+                if (best_t < 0 || t < best_t || (t == best_t && rank < best_rank)) { best_t = t; best_tri = ~refs.x; best_rank = rank; }
+            }
+        }
+        if (hr && refs.y < 0) {
+            double t;
+            if (TRACE) rec->tri_tests++;
+            if (tri_hit(sc.tris + (~refs.y), o, d, t)) {
+                uint32_t rank = 2u * (uint32_t)node + 1u;
+                if (best_t < 0 || t < best_t || (t == best_t && rank < best_rank)) { best_t = t; best_tri = ~refs.y; best_rank = rank; }
+            }
+        }
+        bool tl = hl && refs.x >= 0;
+        bool tr = hr && refs.y >= 0;
+        if (!tl && !tr) {
+            if (sp == 0) break;
+            --sp;
+            node = (int)stack[sp * CPT_WAVE];
+        } else {
+            node = tl ? refs.x : refs.y;
+            if (tl && tr) {
+                stack[sp * CPT_WAVE] = (uint32_t)refs.y;
+                ++sp;
+                if (TRACE && sp > rec->max_stack) rec->max_stack = sp;
+            }
+        }
+    }
+}
+
+// Shading normal of a hit (reference: src/gpu/GPUTrimesh.cuh:91-108).  The reference computes the
+// barycentric weights inside every triangle test; only the winning hit's are ever used, so they
+// are computed once here from the same expressions.
+__device__ __forceinline__ dvec3 shading_normal(const DScene& sc, int tri, const dvec3& o, const dvec3& d, double t) {
+    const cpt_tri* tp = sc.tris + tri;
+    dvec3 n = dv(tp->n);
+    if (!(tp->flags & CPT_TRI_VERTEX_NORMALS)) return normalize(n);
+    dvec3 a = dv(tp->a), b = dv(tp->b), c = dv(tp->c);
+    dvec3 P = o + d * t;
+    double alpha = length(cross(b - P, c - P));
+    double beta = length(cross(P - a, c - a));
+    double denom = length(cross(b - a, c - a));
+    alpha /= denom;
+    beta /= denom;
+    const cpt_tri_normals* tn = sc.tnorm + tri;
+    return normalize(alpha * dv(tn->na) + beta * dv(tn->nb) + (1 - alpha - beta) * dv(tn->nc));
+}
+
+// ---- counter RNG -----------------------------------------------------------------------
+// Philox-4x32-10 keyed by the seed and addressed by (pixel, sample, bounce, stream): any path's
+// numbers can be produced anywhere, in any order, on any GPU.  It stands in for the reference's
+// per-pixel XORWOW state (curand_init(1984, pixel, 0), reference: src/path_tracer.cu:412).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// 53 random bits -> (0,1], the range of curand_uniform_double (reference: src/path_tracer.cu:282)
+__device__ __forceinline__ double u01_open0(uint32_t lo, uint32_t hi) {
+    uint64_t bits = (((uint64_t)hi << 32) | lo) >> 11;
+    return (double)(bits + 1) * (1.0 / 9007199254740992.0);
+}
+#define CPT_STREAM_SELECT 0u   // (lobe choice, Fresnel choice)
+#define CPT_STREAM_COSINE 1u   // (r1, r2) of the cosine-weighted direction
+#define CPT_STREAM_ROULETTE 2u // (survival, -)
+#define CPT_BOUNCE_CAMERA 0xFFFFFFFFu
+__device__ __forceinline__ void draw2(const DParams& P, uint32_t pixel, uint32_t sample, uint32_t bounce,
+                                      uint32_t stream, double& a, double& b) {
+    uint32_t r[4];
+    philox4x32_10(pixel, sample, bounce, stream, P.seed_lo, P.seed_hi, r);
+    a = u01_open0(r[0], r[1]);
+    b = u01_open0(r[2], r[3]);
+}
+
+// ---- camera ----------------------------------------------------------------------------
+// reference: src/gpu/GPUCamera.cu:22-32
+__device__ __forceinline__ void camera_ray(const cpt_camera& cam, double x, double y, dvec3& o, dvec3& d) {
+    x -= 0.5;
+    y -= 0.5;
+    d = normalize(dv(cam.look) + x * dv(cam.u) + y * dv(cam.v));
+    o = dv(cam.eye);
+}
+
+// First ray of sample `sample` of pixel (i, j).
+// reference: src/path_tracer.cu:419-431 (pin-hole, jitter in (0,1]); :462-479 (thin lens, keeping
+// the reference's lens offset range (0, aperture] on both axes).
+__device__ __forceinline__ void first_ray(const DScene& sc, const DParams& P, int i, int j, int sample, dvec3& o,
+                                          dvec3& d) {
+    double ja, jb;
+    draw2(P, (uint32_t)(i + j * P.w), (uint32_t)sample, CPT_BOUNCE_CAMERA, CPT_STREAM_SELECT, ja, jb);
+    if (!P.dof) {
+        double newI = i + ja, newJ = j + jb;
+        camera_ray(sc.cam, newI / double(P.w), newJ / double(P.h), o, d);
+    } else {
+        dvec3 to, td;
+        camera_ray(sc.cam, double(i) / double(P.w), double(j) / double(P.h), to, td);
+        dvec3 focal = to + (P.focal_distance * td);
+        double iShift = ja, jShift = jb;
+        iShift *= (2 * P.aperture) - P.aperture;
+        jShift *= (2 * P.aperture) - P.aperture;
+        dvec3 eye = dv(sc.cam.eye) + dv(sc.cam.u) * iShift + dv(sc.cam.v) * jShift;
+        o = eye;
+        d = normalize(focal - eye);
+    }
+}
+
+// ---- one bounce --------------------------------------------------------------------------
+#define CPT_PI 3.14159265358979311600  // reference: src/RayTracer.h:5
+
+// reference: src/path_tracer.cu:242-253
+__device__ __forceinline__ dvec3 cosine_hemisphere(const dvec3& normal, double xa, double xb) {
+    double r1 = 2 * CPT_PI * xa;
+    double r2 = xb;
+    double r2s = sqrt(r2);
+    dvec3 w = normal;
+    dvec3 u = normalize(cross((fabs(w.x) > .1 ? dv(0, 1, 0) : dv(1, 0, 0)), w));
+    dvec3 v = cross(w, u);
+    return normalize(u * cos(r1) * r2s + v * sin(r1) * r2s + w * sqrt(1 - r2));
+}
+
+struct PathRegs {  // a path's live state between bounces
+    dvec3 o, d;      // current ray
+    double medium;   // refractive index of the medium the ray travels in (1.0 = air)
+    dvec3 atten;     // throughput
+    dvec3 color;     // radiance gathered so far
+};
+
+// Russian roulette before bounce `bounce` (off in the reference, which has it commented out at
+// src/path_tracer.cu:38-46: survive with probability 0.30 once min(3, depth) bounces are done).
+// Returns false when the path dies.
+__device__ __forceinline__ bool roulette(const DParams& P, uint32_t pixel, uint32_t sample, int bounce, PathRegs& s) {
+    if (!P.rr || bounce < (P.depth < 3 ? P.depth : 3)) return true;
+    const double probRR = 0.30;
+    double xa, xb;
+    draw2(P, pixel, sample, (uint32_t)bounce, CPT_STREAM_ROULETTE, xa, xb);
+    if (xa >= probRR) return false;
+    s.atten = s.atten * (1 / probRR);
+    return true;
+}
+
+// Process the intersection (t, tri) found for s's current ray at bounce `bounce`: add emission,
+// choose a lobe, replace the ray and scale the throughput.  Returns true when the path goes on.
+// reference: src/path_tracer.cu:263-397; termination test as src/improved_path_tracer.cu:80.
+__device__ __forceinline__ bool shade_bounce(const DScene& sc, const DParams& P, uint32_t pixel, uint32_t sample,
+                                             int bounce, double t, int tri, PathRegs& s) {
+    if (tri < 0) return false;  // the reference re-intersects the same missing ray until the loop ends
+    const cpt_material* m = sc.mats + sc.tris[tri].material;
+    dvec3 ke = dv(m->ke), kd = dv(m->kd), ks = dv(m->ks), kt = dv(m->kt);
+    s.color = s.color + ke * s.atten;
+    if (!(m->flags & (CPT_MAT_DIFF | CPT_MAT_SPEC | CPT_MAT_TRANS))) return false;
+    if (bounce >= P.depth) return false;  // the new ray would never be traced
+    dvec3 N = shading_normal(sc, tri, s.o, s.d, t);
+    double spec = (ks.x + ks.y + ks.z) / 3.0;
+    double diff = (kd.x + kd.y + kd.z) / 3.0;
+    double trans = (kt.x + kt.y + kt.z) / 3.0;
+    double total = spec + diff + trans;
+    double diffProb = diff / total, specProb = spec / total, transProb = trans / total;
+    double prob, sampleFresnel;
+    draw2(P, pixel, sample, (uint32_t)bounce, CPT_STREAM_SELECT, prob, sampleFresnel);
+    dvec3 at = s.o + (t * s.d);
+    if (prob < diffProb) {
+        dvec3 normal = normalize(N);
+        double xa, xb;
+        draw2(P, pixel, sample, (uint32_t)bounce, CPT_STREAM_COSINE, xa, xb);
+        dvec3 rand_dir = cosine_hemisphere(normal, xa, xb);
+        const double pdf = 1 / CPT_PI, theta = 1;
+        s.o = at + normal * 1e-12;
+        s.d = rand_dir;
+        s.medium = 1.0;
+        dvec3 brdf = kd / CPT_PI;
+        s.atten = s.atten * (brdf * theta / (pdf * diffProb));
+    } else if (prob < diffProb + specProb) {
+        dvec3 w_in = normalize(s.d);
+        dvec3 normal = normalize(N);
+        if (s.medium != 1.0) normal = normal * -1.0;
+        dvec3 w_normal = dot(w_in, normal) * normal;
+        dvec3 w_tan = w_in - w_normal;
+        dvec3 w_ref = normalize(-w_normal + w_tan);
+        s.o = at + normal * 1e-12;
+        s.d = w_ref;
+        s.medium = 1.0;  // the reference builds a fresh Ray here, which resets the medium (path_tracer.cu:306)
+        s.atten = s.atten * (ks * 1.0 / specProb);
+    } else {
+        dvec3 w_in = s.d;
+        dvec3 normal = N;
+        double n1, n2;
+        dvec3 tr = dv(1, 1, 1);
+        if (s.medium == 1.0) {
+            n1 = s.medium;
+            n2 = m->index;
+        } else {
+            n1 = m->index;
+            n2 = 1.0;
+            normal = normal * -1.0;
+            tr = dv(pow(kt.x, t), pow(kt.y, t), pow(kt.z, t));
+        }
+        double r0 = (n1 - n2) / (n1 + n2);
+        r0 *= r0;
+        double n = n1 / n2;
+        w_in = -normalize(w_in);
+        double cosI = dot(normal, w_in);
+        double cosR = 1 - n * n * (1 - cosI * cosI);
+        if (cosR >= 0) {
+            double reflCoeff = r0 + (1 - r0) * pow((1 - cosI), 5.0);
+            if (sampleFresnel > reflCoeff) {
+                double cosT = sqrt(cosR);
+                dvec3 refrac = (n * cosI - cosT) * normal - n * w_in;
+                s.o = at - normal * 1e-12;
+                s.d = refrac;
+                s.medium = n2;
+                s.atten = s.atten * tr;
+            } else {
+                dvec3 w2 = s.d;
+                dvec3 nn = N;
+                if (s.medium != 1.0) nn = nn * -1.0;
+                dvec3 w_normal = dot(w2, nn) * nn;
+                dvec3 w_tan = w2 - w_normal;
+                dvec3 w_ref = normalize(-w_normal + w_tan);
+                s.o = at + nn * 1e-12;
+                s.d = w_ref;  // medium kept
+                s.atten = s.atten * ks;
+            }
+        } else {
+            dvec3 w2 = s.d;
+            dvec3 w_normal = dot(w2, normal) * normal;
+            dvec3 w_tan = w2 - w_normal;
+            dvec3 w_ref = normalize(-w_normal + w_tan);
+            s.o = at + normal * 1e-12;
+            s.d = w_ref;  // medium kept
+            s.atten = s.atten * (dv(m->kr) * tr);
+        }
+        s.atten = s.atten * (1 / transProb);
+    }
+    return true;
+}
+
+// Pixel slot <-> pixel.  Slots enumerate 8x8 pixel tiles, so the 64 lanes of a wave that
+// processes 64 consecutive slots hold one tile: neighbouring first rays, one coalesced block of
+// state.  Slots whose pixel falls outside the image are never generated.
+__device__ __forceinline__ bool slot_to_pixel(const DParams& P, int slot, int& i, int& j) {
+    int tile = slot >> 6, in = slot & 63;
+    int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    i = tx * 8 + (in & 7);
+    j = ty * 8 + (in >> 3);
+    return i < P.w && j < P.h;
+}

@@ -1,0 +1,362 @@
+// gfx950 kernels of the path tracer and their launchers.
+//
+// Wavefront pipeline (the product): a batch holds S samples of every pixel as S * n_pix_slots path
+// slots.  generate writes every slot's first ray; then, once per bounce, extend intersects the rays
+// of the live queue and shade consumes the hits, writes the next rays and compacts the survivors
+// into the next queue (one ballot + popcount prefix + one atomic per wave).  resolve folds the
+// batch's per-path radiance into the per-pixel accumulation buffer in sample order, so the sum a
+// pixel receives is the same sequence of fp64 additions whatever the batch size.
+//
+// Path state is structure-of-arrays in HBM, indexed by slot; slots enumerate 8x8 pixel tiles so a
+// wave's 64 first rays are neighbours and its state accesses are contiguous.
+#include <hip/hip_runtime.h>
+
+#include "device_core.h"
+#include "launch.h"
+
+#define CPT_BLOCK 256
+#define CPT_WAVES_PER_BLOCK (CPT_BLOCK / CPT_WAVE)
+
+// LDS traversal stacks for one workgroup: [wave][entry][lane]
+#define CPT_DECLARE_STACK                                                                  \
+    __shared__ uint32_t s_stack[CPT_WAVES_PER_BLOCK][CPT_STACK_ENTRIES][CPT_WAVE];          \
+    uint32_t* my_stack = &s_stack[threadIdx.x / CPT_WAVE][0][threadIdx.x % CPT_WAVE];
+
+__device__ __forceinline__ void load_path(const PathArrays& A, int slot, PathRegs& s) {
+    s.o = dv(A.ox[slot], A.oy[slot], A.oz[slot]);
+    s.d = dv(A.dx[slot], A.dy[slot], A.dz[slot]);
+    s.medium = A.medium[slot];
+    s.atten = dv(A.ax[slot], A.ay[slot], A.az[slot]);
+    s.color = dv(A.cx[slot], A.cy[slot], A.cz[slot]);
+}
+__device__ __forceinline__ void store_ray(const PathArrays& A, int slot, const PathRegs& s) {
+    A.ox[slot] = s.o.x; A.oy[slot] = s.o.y; A.oz[slot] = s.o.z;
+    A.dx[slot] = s.d.x; A.dy[slot] = s.d.y; A.dz[slot] = s.d.z;
+    A.medium[slot] = s.medium;
+    A.ax[slot] = s.atten.x; A.ay[slot] = s.atten.y; A.az[slot] = s.atten.z;
+}
+__device__ __forceinline__ void store_color(const PathArrays& A, int slot, const PathRegs& s) {
+    A.cx[slot] = s.color.x; A.cy[slot] = s.color.y; A.cz[slot] = s.color.z;
+}
+
+// Append to a queue: the wave's survivors take consecutive places behind one atomic.
+// Stands in for thrust::partition over whole path records (reference: src/improved_path_tracer.cu:321-324);
+// here only 4-byte slot indices move.
+__device__ __forceinline__ void wave_append(uint32_t* queue, uint32_t* counter, bool keep, uint32_t value) {
+    uint64_t mask = __ballot(keep);
+    if (mask == 0) return;
+    uint32_t lane = __lane_id();
+    uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    int leader = __ffsll((unsigned long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (keep) queue[base + before] = value;
+}
+
+// ---- generate ----------------------------------------------------------------------------
+// One thread per slot of the batch: slot = k * n_pix_slots + pixel slot, sample = batch_s0 + k.
+// reference: initRays (src/improved_path_tracer.cu:221-251)
+__global__ void __launch_bounds__(CPT_BLOCK) k_generate(DScene sc, DParams P, PathArrays A, int batch_s0, int batch_n,
+                                                        uint32_t* queue, uint32_t* counter) {
+    int total = batch_n * P.n_pix_slots;
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += gridDim.x * blockDim.x) {
+        int k = slot / P.n_pix_slots, ps = slot - k * P.n_pix_slots;
+        int i, j;
+        bool live = slot_to_pixel(P, ps, i, j);
+        PathRegs s;
+        s.color = dv(0, 0, 0);
+        if (live) {
+            int sample = batch_s0 + k;
+            first_ray(sc, P, i, j, sample, s.o, s.d);
+            s.medium = 1.0;
+            s.atten = dv(1, 1, 1);
+            live = roulette(P, (uint32_t)(i + j * P.w), (uint32_t)sample, 0, s);
+            store_ray(A, slot, s);
+        }
+        store_color(A, slot, s);
+        wave_append(queue, counter, live, (uint32_t)slot);
+    }
+}
+
+// ---- extend --------------------------------------------------------------------------------
+// Closest hit for every slot in the live queue.
+// reference: the intersection half of pathTrace (src/improved_path_tracer.cu:56-76)
+template <bool COUNT>
+__global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, PathArrays A, const uint32_t* __restrict__ queue,
+                                                      const uint32_t* __restrict__ counter, unsigned long long* work) {
+    CPT_DECLARE_STACK
+    uint32_t n = *counter;
+    unsigned long long steps = 0, tris = 0;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        int slot = (int)queue[q];
+        dvec3 o = dv(A.ox[slot], A.oy[slot], A.oz[slot]);
+        dvec3 d = dv(A.dx[slot], A.dy[slot], A.dz[slot]);
+        double t;
+        int tri;
+        if (COUNT) {
+            TraceRec rec = {0, 0, 0, 0, 0, nullptr};
+            traverse<true>(sc, o, d, my_stack, t, tri, &rec);
+            steps += (unsigned long long)rec.node_steps;
+            tris += (unsigned long long)rec.tri_tests;
+        } else {
+            traverse<false>(sc, o, d, my_stack, t, tri, nullptr);
+        }
+        A.hit_t[slot] = t;
+        A.hit_tri[slot] = tri;
+    }
+    if (COUNT) {
+        if (steps) atomicAdd(&work[3], steps);
+        if (tris) atomicAdd(&work[4], tris);
+    }
+}
+
+// ---- shade + compact -------------------------------------------------------------------------
+// reference: the shading half of pathTrace (src/improved_path_tracer.cu:77-215)
+template <bool COUNT>
+__global__ void __launch_bounds__(CPT_BLOCK) k_shade(DScene sc, DParams P, PathArrays A, int batch_s0, int bounce,
+                                                     const uint32_t* __restrict__ queue_in,
+                                                     const uint32_t* __restrict__ counter_in, uint32_t* queue_out,
+                                                     uint32_t* counter_out, unsigned long long* work) {
+    uint32_t n = *counter_in;
+    uint32_t n_round = (n + CPT_WAVE - 1) / CPT_WAVE * CPT_WAVE;  // whole waves reach wave_append together
+    unsigned long long hits = 0, segs = 0;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_round; q += gridDim.x * blockDim.x) {
+        bool go = false;
+        int slot = 0;
+        if (q < n) {
+            slot = (int)queue_in[q];
+            int k = slot / P.n_pix_slots, ps = slot - k * P.n_pix_slots;
+            int i, j;
+            slot_to_pixel(P, ps, i, j);
+            uint32_t pixel = (uint32_t)(i + j * P.w), sample = (uint32_t)(batch_s0 + k);
+            PathRegs s;
+            load_path(A, slot, s);
+            double t = A.hit_t[slot];
+            int tri = A.hit_tri[slot];
+            if (COUNT) { segs++; hits += (tri >= 0); }
+            go = shade_bounce(sc, P, pixel, sample, bounce, t, tri, s);
+            if (go) go = roulette(P, pixel, sample, bounce + 1, s);
+            if (go) store_ray(A, slot, s);
+            store_color(A, slot, s);
+        }
+        wave_append(queue_out, counter_out, go, (uint32_t)slot);
+    }
+    if (COUNT) {
+        if (segs) atomicAdd(&work[1], segs);
+        if (hits) atomicAdd(&work[2], hits);
+    }
+}
+
+// ---- resolve ---------------------------------------------------------------------------------
+// accum[pixel] += color of sample batch_s0, then batch_s0 + 1, ... : the order pathTraceKernel sums
+// its samples in (reference: src/path_tracer.cu:419-435).
+__global__ void __launch_bounds__(CPT_BLOCK) k_resolve(DParams P, PathArrays A, int batch_n, double* __restrict__ accum) {
+    for (int ps = blockIdx.x * blockDim.x + threadIdx.x; ps < P.n_pix_slots; ps += gridDim.x * blockDim.x) {
+        int i, j;
+        if (!slot_to_pixel(P, ps, i, j)) continue;
+        double* px = accum + 3 * (size_t)(i + j * P.w);
+        dvec3 sum = dv(px[0], px[1], px[2]);
+        for (int k = 0; k < batch_n; ++k) {
+            int slot = k * P.n_pix_slots + ps;
+            sum = sum + dv(A.cx[slot], A.cy[slot], A.cz[slot]);
+        }
+        px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
+    }
+}
+
+// ---- one thread per pixel ----------------------------------------------------------------------
+// All samples and bounces of a pixel in registers; the per-pixel loop of the reference's live kernel.
+// reference: pathTraceKernel / pathTraceDOFKernel (src/path_tracer.cu:403-492)
+template <bool COUNT>
+__global__ void __launch_bounds__(CPT_BLOCK) k_megakernel(DScene sc, DParams P, double* __restrict__ accum,
+                                                          unsigned long long* work) {
+    CPT_DECLARE_STACK
+    unsigned long long steps = 0, tris = 0, hits = 0, segs = 0;
+    for (int ps = blockIdx.x * blockDim.x + threadIdx.x; ps < P.n_pix_slots; ps += gridDim.x * blockDim.x) {
+        int i, j;
+        if (!slot_to_pixel(P, ps, i, j)) continue;
+        uint32_t pixel = (uint32_t)(i + j * P.w);
+        double* px = accum + 3 * (size_t)pixel;
+        dvec3 sum = dv(px[0], px[1], px[2]);
+        for (int sample = P.s0; sample < P.s1; ++sample) {
+            PathRegs s;
+            first_ray(sc, P, i, j, sample, s.o, s.d);
+            s.medium = 1.0;
+            s.atten = dv(1, 1, 1);
+            s.color = dv(0, 0, 0);
+            bool go = roulette(P, pixel, (uint32_t)sample, 0, s);
+            for (int bounce = 0; go && bounce <= P.depth; ++bounce) {
+                double t;
+                int tri;
+                if (COUNT) {
+                    TraceRec rec = {0, 0, 0, 0, 0, nullptr};
+                    traverse<true>(sc, s.o, s.d, my_stack, t, tri, &rec);
+                    steps += (unsigned long long)rec.node_steps;
+                    tris += (unsigned long long)rec.tri_tests;
+                    segs++;
+                    hits += (tri >= 0);
+                } else {
+                    traverse<false>(sc, s.o, s.d, my_stack, t, tri, nullptr);
+                }
+                go = shade_bounce(sc, P, pixel, (uint32_t)sample, bounce, t, tri, s);
+                if (go) go = roulette(P, pixel, (uint32_t)sample, bounce + 1, s);
+            }
+            sum = sum + s.color;
+        }
+        px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
+    }
+    if (COUNT) {
+        if (segs) atomicAdd(&work[1], segs);
+        if (hits) atomicAdd(&work[2], hits);
+        if (steps) atomicAdd(&work[3], steps);
+        if (tris) atomicAdd(&work[4], tris);
+    }
+}
+
+// ---- tonemap -----------------------------------------------------------------------------------
+// reference: src/path_tracer.cu:436-443
+__global__ void __launch_bounds__(CPT_BLOCK) k_tonemap(const double* __restrict__ accum, int n_values, int spp,
+                                                       uint8_t* __restrict__ rgb) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_values; k += gridDim.x * blockDim.x) {
+        double c = accum[k] / spp;
+        c = fmin(fmax(c, 0.0), 1.0);
+        rgb[k] = (uint8_t)(int)(255.0 * c);
+    }
+}
+
+// ---- parity hooks ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(CPT_BLOCK) k_trace_rays(DScene sc, int n, const double* __restrict__ o3,
+                                                          const double* __restrict__ d3, int* tri_out, double* t_out,
+                                                          double* normal_out, unsigned long long* vhash_out,
+                                                          int* counts_out, uint8_t* bitmap, int bitmap_stride) {
+    CPT_DECLARE_STACK
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        dvec3 o = dv(o3 + 3 * (size_t)r), d = dv(d3 + 3 * (size_t)r);
+        TraceRec rec = {0, 0, 0, 0, 0, bitmap ? bitmap + (size_t)r * bitmap_stride : nullptr};
+        double t;
+        int tri;
+        traverse<true>(sc, o, d, my_stack, t, tri, &rec);
+        tri_out[r] = tri;
+        t_out[r] = t;
+        if (normal_out) {
+            dvec3 N = tri >= 0 ? shading_normal(sc, tri, o, d, t) : dv(0, 0, 0);
+            normal_out[3 * (size_t)r] = N.x; normal_out[3 * (size_t)r + 1] = N.y; normal_out[3 * (size_t)r + 2] = N.z;
+        }
+        if (vhash_out) vhash_out[r] = rec.visit_hash;
+        if (counts_out) {
+            counts_out[4 * (size_t)r] = rec.node_steps; counts_out[4 * (size_t)r + 1] = rec.box_tests;
+            counts_out[4 * (size_t)r + 2] = rec.tri_tests; counts_out[4 * (size_t)r + 3] = rec.max_stack;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(CPT_BLOCK) k_camera_rays(DScene sc, int w, int h, double jx, double jy, double* o3,
+                                                           double* d3) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < w * h; p += gridDim.x * blockDim.x) {
+        int i = p % w, j = p / w;
+        dvec3 o, d;
+        camera_ray(sc.cam, (i + jx) / double(w), (j + jy) / double(h), o, d);
+        o3[3 * (size_t)p] = o.x; o3[3 * (size_t)p + 1] = o.y; o3[3 * (size_t)p + 2] = o.z;
+        d3[3 * (size_t)p] = d.x; d3[3 * (size_t)p + 1] = d.y; d3[3 * (size_t)p + 2] = d.z;
+    }
+}
+
+__global__ void __launch_bounds__(CPT_BLOCK) k_path_radiance(DScene sc, DParams P, int n, const int* __restrict__ ijs,
+                                                             double* rad) {
+    CPT_DECLARE_STACK
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        int i = ijs[3 * r], j = ijs[3 * r + 1], sample = ijs[3 * r + 2];
+        uint32_t pixel = (uint32_t)(i + j * P.w);
+        PathRegs s;
+        first_ray(sc, P, i, j, sample, s.o, s.d);
+        s.medium = 1.0;
+        s.atten = dv(1, 1, 1);
+        s.color = dv(0, 0, 0);
+        bool go = roulette(P, pixel, (uint32_t)sample, 0, s);
+        for (int bounce = 0; go && bounce <= P.depth; ++bounce) {
+            double t;
+            int tri;
+            traverse<false>(sc, s.o, s.d, my_stack, t, tri, nullptr);
+            go = shade_bounce(sc, P, pixel, (uint32_t)sample, bounce, t, tri, s);
+            if (go) go = roulette(P, pixel, (uint32_t)sample, bounce + 1, s);
+        }
+        rad[3 * (size_t)r] = s.color.x; rad[3 * (size_t)r + 1] = s.color.y; rad[3 * (size_t)r + 2] = s.color.z;
+    }
+}
+
+__global__ void k_probe_math(int n, const double* a, const double* b, double* out_sqrt, double* out_div) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        out_sqrt[k] = sqrt(a[k]);
+        out_div[k] = a[k] / (b ? b[k] : 3.0);
+    }
+}
+
+__global__ void k_probe_rng(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out,
+                            double* out_u) {
+    uint32_t r[4];
+    philox4x32_10(c0, c1, c2, c3, k0, k1, r);
+    for (int q = 0; q < 4; ++q) out[q] = r[q];
+    out_u[0] = u01_open0(r[0], r[1]);
+    out_u[1] = u01_open0(r[2], r[3]);
+}
+
+// ---- launchers (called from the C ABI in capi.cpp) ------------------------------------------------
+static inline int grid_for(long long n_threads, int max_blocks) {
+    long long b = (n_threads + CPT_BLOCK - 1) / CPT_BLOCK;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int batch_n,
+                     uint32_t* queue, uint32_t* counter) {
+    int g = grid_for((long long)batch_n * P.n_pix_slots, L.max_blocks);
+    hipLaunchKernelGGL(k_generate, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, A, batch_s0, batch_n, queue, counter);
+}
+void launch_extend(const LaunchCfg& L, const DScene& sc, const PathArrays& A, const uint32_t* queue, const uint32_t* counter,
+                   long long max_entries, unsigned long long* work) {
+    int g = grid_for(max_entries, L.max_blocks);
+    if (work) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, A, queue, counter, work);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, A, queue, counter, work);
+}
+void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int bounce,
+                  const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* queue_out, uint32_t* counter_out,
+                  long long max_entries, unsigned long long* work) {
+    int g = grid_for(max_entries, L.max_blocks);
+    if (work) hipLaunchKernelGGL(k_shade<true>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, queue_out, counter_out, work);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, queue_out, counter_out, work);
+}
+void launch_resolve(const LaunchCfg& L, const DParams& P, const PathArrays& A, int batch_n, double* accum) {
+    int g = grid_for(P.n_pix_slots, L.max_blocks);
+    hipLaunchKernelGGL(k_resolve, dim3(g), dim3(CPT_BLOCK), 0, L.stream, P, A, batch_n, accum);
+}
+void launch_megakernel(const LaunchCfg& L, const DScene& sc, const DParams& P, double* accum, unsigned long long* work) {
+    int g = grid_for(P.n_pix_slots, 1 << 30);
+    if (work) hipLaunchKernelGGL(k_megakernel<true>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, accum, work);
+    else hipLaunchKernelGGL(k_megakernel<false>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, accum, work);
+}
+void launch_tonemap(const LaunchCfg& L, const double* accum, int n_values, int spp, uint8_t* rgb) {
+    int g = grid_for(n_values, L.max_blocks);
+    hipLaunchKernelGGL(k_tonemap, dim3(g), dim3(CPT_BLOCK), 0, L.stream, accum, n_values, spp, rgb);
+}
+void launch_trace_rays(const LaunchCfg& L, const DScene& sc, int n, const double* o3, const double* d3, int* tri, double* t,
+                       double* normal, unsigned long long* vhash, int* counts, uint8_t* bitmap, int bitmap_stride) {
+    int g = grid_for(n, L.max_blocks);
+    hipLaunchKernelGGL(k_trace_rays, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, n, o3, d3, tri, t, normal, vhash, counts, bitmap, bitmap_stride);
+}
+void launch_camera_rays(const LaunchCfg& L, const DScene& sc, int w, int h, double jx, double jy, double* o3, double* d3) {
+    int g = grid_for((long long)w * h, L.max_blocks);
+    hipLaunchKernelGGL(k_camera_rays, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, w, h, jx, jy, o3, d3);
+}
+void launch_path_radiance(const LaunchCfg& L, const DScene& sc, const DParams& P, int n, const int* ijs, double* rad) {
+    int g = grid_for(n, L.max_blocks);
+    hipLaunchKernelGGL(k_path_radiance, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, n, ijs, rad);
+}
+void launch_probe_math(const LaunchCfg& L, int n, const double* a, const double* b, double* s, double* q) {
+    int g = grid_for(n, L.max_blocks);
+    hipLaunchKernelGGL(k_probe_math, dim3(g), dim3(CPT_BLOCK), 0, L.stream, n, a, b, s, q);
+}
+void launch_probe_rng(const LaunchCfg& L, const uint32_t c[4], const uint32_t k[2], uint32_t* out, double* out_u) {
+    hipLaunchKernelGGL(k_probe_rng, dim3(1), dim3(1), 0, L.stream, c[0], c[1], c[2], c[3], k[0], k[1], out, out_u);
+}

@@ -1,0 +1,60 @@
+// Types shared between the kernels (kernels.hip) and the C ABI implementation (capi.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cpt_amd.h"
+
+struct DScene {
+    const cpt_node* __restrict__ nodes;
+    const cpt_tri* __restrict__ tris;
+    const cpt_tri_normals* __restrict__ tnorm;
+    const cpt_material* __restrict__ mats;
+    cpt_camera cam;
+    int n_nodes, n_tris;
+};
+
+struct DParams {  // cpt_render_params plus what the kernels derive from it
+    int w, h, s0, s1, depth;
+    int dof, rr;
+    uint32_t seed_lo, seed_hi;
+    double focal_distance, aperture;
+    int tiles_x, tiles_y;  // 8x8 pixel tiles
+    int n_pix_slots;       // tiles_x*tiles_y*64
+};
+
+
+// Path state of the wavefront pipeline, structure-of-arrays in HBM, one element per slot.
+struct PathArrays {
+    double *ox, *oy, *oz;   // ray origin
+    double *dx, *dy, *dz;   // ray direction
+    double* medium;         // refractive index of the current medium
+    double *ax, *ay, *az;   // throughput
+    double *cx, *cy, *cz;   // radiance gathered by the path
+    double* hit_t;          // extend -> shade
+    int* hit_tri;
+};
+#define CPT_PATH_DOUBLES 14  // doubles per slot in PathArrays
+#define CPT_PATH_BYTES (CPT_PATH_DOUBLES * 8 + 4)
+
+struct LaunchCfg {
+    hipStream_t stream;
+    int max_blocks;  // grid cap for grid-stride kernels
+};
+
+void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int batch_n,
+                     uint32_t* queue, uint32_t* counter);
+void launch_extend(const LaunchCfg& L, const DScene& sc, const PathArrays& A, const uint32_t* queue, const uint32_t* counter,
+                   long long max_entries, unsigned long long* work);
+void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int bounce,
+                  const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* queue_out, uint32_t* counter_out,
+                  long long max_entries, unsigned long long* work);
+void launch_resolve(const LaunchCfg& L, const DParams& P, const PathArrays& A, int batch_n, double* accum);
+void launch_megakernel(const LaunchCfg& L, const DScene& sc, const DParams& P, double* accum, unsigned long long* work);
+void launch_tonemap(const LaunchCfg& L, const double* accum, int n_values, int spp, uint8_t* rgb);
+void launch_trace_rays(const LaunchCfg& L, const DScene& sc, int n, const double* o3, const double* d3, int* tri, double* t,
+                       double* normal, unsigned long long* vhash, int* counts, uint8_t* bitmap, int bitmap_stride);
+void launch_camera_rays(const LaunchCfg& L, const DScene& sc, int w, int h, double jx, double jy, double* o3, double* d3);
+void launch_path_radiance(const LaunchCfg& L, const DScene& sc, const DParams& P, int n, const int* ijs, double* rad);
+void launch_probe_math(const LaunchCfg& L, int n, const double* a, const double* b, double* s, double* q);
+void launch_probe_rng(const LaunchCfg& L, const uint32_t c[4], const uint32_t k[2], uint32_t* out, double* out_u);

@@ -1,0 +1,139 @@
+// bin/ray: the reference's command line for the path tracer,
+//   ray [options] input.ray output.png
+// with the reference's option letters (reference: src/ui/CommandLineUI.cpp:23-137, src/main.cu:22-41):
+//   -r depth  -w width  -s samples  -g (GPU)  -j json  -c cubemap  -h
+// and a few long options for what the reference fixes at compile time.
+#include <getopt.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+
+#include "png_write.h"
+#include "raytracer.h"
+
+namespace {
+
+struct Cli {
+    int depth = 0;      // reference default: src/ui/TraceUI.h:101
+    int size = 512;     // reference default: src/ui/TraceUI.h:102
+    int samples = 32;   // reference default: src/ui/CommandLineUI.cpp:30
+    bool gpu = false;
+    std::string json, cubemap;
+    cpt::PathTracingOptions pt;
+};
+
+void usage(const char* prog, const Cli& c) {
+    std::cerr << "usage: " << prog << " [options] [input.ray output.png]\n"
+              << "  -r <#>      set recursion level (default " << c.depth << ")\n"
+              << "  -w <#>      set output image width (default " << c.size << ")\n"
+              << "  -j <FILE>   set parameters from JSON file\n"
+              << "  -c <FILE>   one Cubemap file (accepted; the path tracer does not use cubemaps)\n"
+              << "  -g          Enable GPU rendering (MI355X, HIP)\n"
+              << "  -s <#>      Set number of samples per pixel (path tracing)\n"
+              << "  --mode wavefront|mega   work-queue pipeline (default) or one thread per pixel\n"
+              << "  --dof <focal>,<aperture>   thin-lens camera\n"
+              << "  --rr        Russian roulette\n"
+              << "  --seed <#>  random seed (default 1984)\n"
+              << "  --device <#> GPU ordinal (default 0)\n";
+}
+
+// Flat JSON object with numeric values: the keys the reference reads that matter here are
+// "size" and "recursion_depth" (reference: src/ui/TraceUI.cc:46-76).
+bool json_number(const std::string& text, const char* key, double& out) {
+    std::string pat = std::string("\"") + key + "\"";
+    size_t p = text.find(pat);
+    if (p == std::string::npos) return false;
+    p = text.find(':', p + pat.size());
+    if (p == std::string::npos) return false;
+    char* end = nullptr;
+    double v = std::strtod(text.c_str() + p + 1, &end);
+    if (end == text.c_str() + p + 1) return false;
+    out = v;
+    return true;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Cli c;
+    static option longopts[] = {{"mode", required_argument, nullptr, 1000}, {"dof", required_argument, nullptr, 1001},
+                                {"rr", no_argument, nullptr, 1002},         {"seed", required_argument, nullptr, 1003},
+                                {"device", required_argument, nullptr, 1004}, {nullptr, 0, nullptr, 0}};
+    int o;
+    while ((o = getopt_long(argc, argv, "tr:w:hj:c:gs:", longopts, nullptr)) != -1) {
+        switch (o) {
+            case 'r': c.depth = atoi(optarg); break;
+            case 'w': c.size = atoi(optarg); break;
+            case 'j': c.json = optarg; break;
+            case 'c': c.cubemap = optarg; break;
+            case 'h': usage(argv[0], c); return 1;
+            case 'g': c.gpu = true; break;
+            case 's': c.samples = atoi(optarg); break;
+            case 't': break;
+            case 1000:
+                if (!strcmp(optarg, "wavefront")) c.pt.work_queue = true;
+                else if (!strcmp(optarg, "mega")) c.pt.work_queue = false;
+                else { std::cerr << "unknown mode '" << optarg << "'\n"; return 1; }
+                break;
+            case 1001:
+                if (sscanf(optarg, "%lf,%lf", &c.pt.focal_distance, &c.pt.aperture) != 2) { std::cerr << "--dof wants <focal>,<aperture>\n"; return 1; }
+                c.pt.use_dof = true;
+                break;
+            case 1002: c.pt.russian_roulette = true; break;
+            case 1003: c.pt.seed = strtoull(optarg, nullptr, 10); break;
+            case 1004: c.pt.device = atoi(optarg); break;
+            default:
+                std::cerr << "Invalid argument: '" << o << "'." << std::endl;
+                usage(argv[0], c);
+                return 1;
+        }
+    }
+    if (!c.json.empty()) {
+        std::ifstream f(c.json);
+        std::stringstream ss;
+        ss << f.rdbuf();
+        double v;
+        if (json_number(ss.str(), "size", v)) c.size = (int)v;
+        if (json_number(ss.str(), "recursion_depth", v)) c.depth = (int)v;
+    }
+    if (optind >= argc - 1) {
+        std::cerr << "no input and/or output name." << std::endl;
+        return 1;
+    }
+    const char* rayName = argv[optind];
+    const char* imgName = argv[optind + 1];
+
+    cpt::RayTracer rt;
+    rt.options = c.pt;
+    if (!rt.loadScene(rayName)) {
+        std::cerr << "Unable to load ray file '" << rayName << "'" << std::endl;
+        return 1;
+    }
+    int width = c.size;
+    int height = (int)(width / rt.aspectRatio() + 0.5);
+    if (width < 1 || height < 1 || c.samples < 1 || c.depth < 0) { std::cerr << "bad size, samples or depth" << std::endl; return 1; }
+    rt.traceSetup(width, height, c.gpu, c.samples, c.depth);
+    auto t0 = std::chrono::steady_clock::now();
+    rt.traceImage(width, height);
+    rt.waitRender();
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rt.failed()) {
+        std::cerr << "render failed: " << rt.lastError() << std::endl;
+        return 2;
+    }
+    unsigned char* buf;
+    rt.getBuffer(buf, width, height);
+    std::string err;
+    if (!cpt::write_image(imgName, width, height, buf, err)) {
+        std::cerr << err << std::endl;
+        return 3;
+    }
+    std::cout << "total time = " << secs << " seconds, " << (double)width * height * c.samples / secs / 1e6 << " Mpaths/s" << std::endl;
+    return 0;
+}

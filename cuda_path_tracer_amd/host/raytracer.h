@@ -1,0 +1,57 @@
+// Host-side render driver with the reference's RayTracer interface for the path-tracing path
+// (reference: src/RayTracer.h:30-96): loadScene, traceSetup, traceImage, waitRender, getBuffer,
+// aspectRatio, plus the two GPU entry points traceImageGPU and betterPathTracing.  Each of those
+// two is now one call through the C ABI of libcpt_amd.so.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "cpt_amd.h"
+#include "flatten.h"
+
+namespace cpt {
+
+struct PathTracingOptions {  // what the reference hard-codes in traceImageGPU (src/path_tracer.cu:509-514)
+    bool use_dof = false;
+    double focal_distance = 8.5;
+    double aperture = 0.6;
+    bool russian_roulette = false;
+    bool work_queue = true;  // true: betterPathTracing (wavefront); false: traceImageGPU (one thread per pixel)
+    unsigned long long seed = 1984;
+    int device = 0;
+};
+
+class RayTracer {
+public:
+    RayTracer();
+    ~RayTracer();
+
+    bool loadScene(const char* fn);
+    bool sceneLoaded() const { return scene_ != nullptr; }
+    double aspectRatio() const;
+
+    void traceSetup(int w, int h, bool useGPU, int pathTracingSamples, int depth);
+    void traceImage(int w, int h);
+    void traceImageGPU(int w, int h);       // reference: src/path_tracer.cu:507-551
+    void betterPathTracing(int w, int h);   // reference: src/improved_path_tracer.cu:277-347
+    void waitRender() {}                    // the GPU path is synchronous (reference: src/RayTracer.cpp:735-752)
+    void getBuffer(unsigned char*& buf, int& w, int& h);
+
+    PathTracingOptions options;
+    const std::string& lastError() const { return error_; }
+    bool failed() const { return !error_.empty(); }
+
+private:
+    void renderGPU(int w, int h, int mode);
+    std::unique_ptr<FlatScene> scene_;
+    cpt_ctx* ctx_ = nullptr;
+    bool uploaded_ = false;
+    std::vector<unsigned char> buffer_;
+    int buffer_width_ = 0, buffer_height_ = 0;
+    bool useGPU_ = false;
+    int samples_per_pixel_ = 32, depth_ = 0;
+    std::string error_;
+};
+
+}  // namespace cpt

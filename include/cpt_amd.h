@@ -1,0 +1,203 @@
+/* cpt_amd.h -- C ABI of the MI355X (gfx950) path-tracing library, libcpt_amd.so.
+ *
+ * This is the drop-in boundary for the reference's GPU render path.  The reference has no
+ * FFI: the seam is the member call RayTracer::traceImage -> traceImageGPU(w, h)
+ * (reference: src/RayTracer.cpp:698-707, src/path_tracer.cu:507-551) and the dormant
+ * RayTracer::betterPathTracing(w, h) (src/improved_path_tracer.cu:277-347).  Everything those
+ * two functions do after "the scene and its BVH exist on the host" is behind these entry
+ * points: plain pointers and sizes, int status codes, no exceptions, no exit(), no globals.
+ *
+ * Conventions
+ *   - every call returns CPT_OK (0) or a negative CPT_E* code; cpt_last_error() gives text.
+ *   - pointers named h_* are host memory, d_* are device memory on the context's GPU.
+ *   - images are RGB, row j = 0 is the BOTTOM row (camera up), index (i + j*w)*3, exactly the
+ *     reference's RayTracer::buffer (src/RayTracer.h:82, src/path_tracer.cu:440-443).
+ *   - all arithmetic is IEEE binary64 without FMA contraction.
+ *   - a context is bound to one GPU and must be used from one host thread at a time.
+ */
+#ifndef CPT_AMD_H
+#define CPT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPT_OK 0
+#define CPT_EINVAL (-1)   /* bad argument / scene failed validation            */
+#define CPT_EHIP (-2)     /* a HIP runtime call failed                         */
+#define CPT_ENOSCENE (-3) /* render/trace before cpt_upload_scene              */
+#define CPT_ELIMIT (-4)   /* a compiled-in limit would be exceeded             */
+
+/* ---- flat scene records (host fills them, the library copies them to HBM) ------------- */
+
+/* One expanded internal BVH node: both child boxes, both child references.  128 bytes,
+ * 128-byte aligned = one cache line pair per traversal step.
+ * Replaces GPU::BVHNode + GPU::BoundingBox (reference: src/gpu/GPUBVH.cuh:17-27,
+ * src/gpu/GPUbb.cuh:10-57), which are 80-byte managed allocations reached by pointer.
+ * Records are stored in preorder of the internal nodes, so record k is the k-th node the
+ * reference's traversal can expand and (2k, 2k+1) is the test rank of its (left, right) child. */
+typedef struct cpt_node {
+    double lbox[6];   /* left child  box: min x,y,z then max x,y,z */
+    double rbox[6];   /* right child box                            */
+    int32_t lref;     /* >= 0: record index of the left child; < 0: leaf, triangle index is ~lref */
+    int32_t rref;
+    int32_t lid;      /* canonical id (preorder over ALL nodes, root = 0) of the left child  */
+    int32_t rid;      /* ... of the right child; used only for visit-set reporting            */
+    int32_t self_id;  /* canonical id of this node                                            */
+    int32_t pad_[3];
+} cpt_node;
+
+/* One triangle as the intersection test needs it.  128 bytes.
+ * Replaces GPU::TrimeshFace (reference: src/gpu/GPUTrimesh.cuh:17-57). */
+typedef struct cpt_tri {
+    double a[3], b[3], c[3]; /* vertices                                      */
+    double n[3];             /* unit face normal, normalize(cross(b-a, c-a))  */
+    int32_t material;        /* index into the material table                 */
+    uint32_t flags;          /* CPT_TRI_*                                     */
+    int32_t pad_[6];
+} cpt_tri;
+#define CPT_TRI_RECUR 1u         /* material is reflective or transmissive: no back-face cull */
+#define CPT_TRI_VERTEX_NORMALS 2u /* interpolate cpt_tri_normals instead of the face normal   */
+
+/* Per-vertex normals of one triangle (read only by shading, only for the winning hit). */
+typedef struct cpt_tri_normals {
+    double na[3], nb[3], nc[3];
+} cpt_tri_normals;
+
+/* Replaces GPU::Material (reference: src/gpu/GPUMaterial.cuh:10-58); one per mesh. */
+typedef struct cpt_material {
+    double ke[3], kd[3], ks[3], kr[3], kt[3];
+    double index;   /* 0.299 r + 0.587 g + 0.114 b of the index triple (GPUMaterial.cuh:21) */
+    uint32_t flags; /* CPT_MAT_* */
+    uint32_t pad_;
+} cpt_material;
+#define CPT_MAT_DIFF 1u
+#define CPT_MAT_SPEC 2u
+#define CPT_MAT_TRANS 4u
+#define CPT_MAT_RECUR 8u
+
+/* Replaces GPU::Camera (reference: src/gpu/GPUCamera.cu:11-32). */
+typedef struct cpt_camera {
+    double eye[3], look[3], u[3], v[3];
+} cpt_camera;
+
+typedef struct cpt_scene_desc {
+    int32_t n_nodes;                 /* internal-node records; 0 for a one-triangle scene */
+    int32_t n_tris;
+    int32_t n_materials;
+    int32_t n_tree_nodes;            /* canonical node count (2*n_tris - 1)               */
+    int32_t tree_height;             /* levels, root = 1                                   */
+    int32_t pad_;
+    const cpt_node* nodes;           /* host arrays, caller-owned, copied by the call      */
+    const cpt_tri* tris;
+    const cpt_tri_normals* tri_normals; /* n_tris entries                                  */
+    const cpt_material* materials;
+    cpt_camera camera;
+} cpt_scene_desc;
+
+/* ---- render parameters ---------------------------------------------------------------- */
+
+#define CPT_MODE_WAVEFRONT 0 /* generate -> extend -> shade -> compact queues (betterPathTracing) */
+#define CPT_MODE_MEGAKERNEL 1 /* one thread per pixel, all samples and bounces (traceImageGPU)    */
+
+typedef struct cpt_render_params {
+    int32_t width, height;
+    int32_t sample_begin, sample_end; /* this call renders sample indices [begin, end) of every pixel */
+    int32_t depth;                    /* -r: a path has at most depth+1 segments                      */
+    int32_t mode;                     /* CPT_MODE_*                                                   */
+    uint64_t seed;                    /* reference seed is 1984 (src/path_tracer.cu:412)              */
+    int32_t dof;                      /* 0: pin-hole; 1: thin lens (src/path_tracer.cu:446-492)       */
+    int32_t russian_roulette;         /* 0 (reference behaviour) or 1                                 */
+    double focal_distance, aperture;  /* reference constants: 8.5, 0.6 (src/path_tracer.cu:512-514)   */
+} cpt_render_params;
+
+typedef struct cpt_stats {
+    uint64_t paths, segments, hits, node_steps, tri_tests; /* counted only when counting is on */
+    uint64_t launches_generate, launches_extend, launches_shade, launches_mega;
+    double ms_generate, ms_extend, ms_shade, ms_mega, ms_total; /* HIP-event time on the render stream */
+    uint64_t iterations;
+} cpt_stats;
+
+typedef struct cpt_ctx cpt_ctx;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+
+/* Create a context on GPU `device`.  Replaces the implicit CUDA context of traceImageGPU. */
+int cpt_create(int device, cpt_ctx** out);
+void cpt_destroy(cpt_ctx* ctx);
+/* Text of the last error on this context (ctx may be NULL: error of the last failed cpt_create). */
+const char* cpt_last_error(const cpt_ctx* ctx);
+/* Launch on this hipStream_t (passed as void*) instead of the context's own stream. */
+int cpt_set_stream(cpt_ctx* ctx, void* hip_stream);
+/* Tuning knobs, by name: "batch_paths" (path slots the wavefront pipeline keeps in flight,
+ * default 2^21) and "max_blocks" (grid cap of the grid-stride kernels, default 8 per CU). */
+int cpt_set_option(cpt_ctx* ctx, const char* key, long long value);
+/* Turn per-launch HIP-event timing and device-side work counters on or off (both default off). */
+int cpt_set_instrumentation(cpt_ctx* ctx, int time_kernels, int count_work);
+
+/* Copy a flattened scene to the GPU.  Replaces `new GPU::Scene(scene)` + `copyBVH(&bvhTree)`
+ * (reference: src/path_tracer.cu:519-520, src/gpu/GPUScene.cuh:25-57, src/gpu/GPUBVH.cu:9-31). */
+int cpt_upload_scene(cpt_ctx* ctx, const cpt_scene_desc* scene);
+
+/* ---- rendering -------------------------------------------------------------------------- */
+
+/* Add the radiance of samples [sample_begin, sample_end) of every pixel to d_accum
+ * (device memory, width*height*3 doubles, layout (i + j*w)*3, caller-owned, e.g. a torch tensor).
+ * Asynchronous on the context's stream unless instrumentation is on.
+ * Replaces the kernel launches of traceImageGPU / betterPathTracing
+ * (reference: src/path_tracer.cu:543-547, src/improved_path_tracer.cu:296-333). */
+int cpt_render(cpt_ctx* ctx, const cpt_render_params* params, double* d_accum);
+
+/* mean over total_spp, clamp to [0,1], (int)(255*c) -> d_rgb (device, width*height*3 bytes).
+ * Replaces the tail of pathTraceKernel (reference: src/path_tracer.cu:436-443). */
+int cpt_tonemap(cpt_ctx* ctx, const double* d_accum, int32_t width, int32_t height, int32_t total_spp,
+                uint8_t* d_rgb);
+
+/* The whole of traceImageGPU in one call: allocate, render all samples, tonemap, copy the RGB8
+ * image into h_rgb (host, width*height*3 bytes), free.  Blocking.
+ * Replaces RayTracer::traceImageGPU(w, h) (reference: src/path_tracer.cu:507-551). */
+int cpt_render_image(cpt_ctx* ctx, const cpt_render_params* params, uint8_t* h_rgb);
+
+/* Wait for everything queued on the context's stream. */
+int cpt_synchronize(cpt_ctx* ctx);
+int cpt_get_stats(cpt_ctx* ctx, cpt_stats* out);
+int cpt_reset_stats(cpt_ctx* ctx);
+
+/* ---- parity hooks ----------------------------------------------------------------------- */
+
+/* Intersect n explicit rays with the scene using exactly the render path's traversal.
+ * Host arrays: h_origin/h_dir n*3 doubles.  Outputs (host): h_tri n (triangle index or -1),
+ * h_t n, h_normal n*3 (shading normal of the hit, nullable), h_visit_hash n (sum over tested
+ * nodes of mix64(canonical id + 1), nullable), h_counts n*4 (node steps, box tests, triangle
+ * tests, deepest stack; nullable), h_bitmap (nullable) n rows of bitmap_stride bytes with bit k
+ * set iff node k's box was tested.
+ * Observes GPU::BVH::traverseIterative (reference: src/gpu/GPUBVH.cu:38-99). */
+int cpt_trace_rays(cpt_ctx* ctx, int32_t n, const double* h_origin, const double* h_dir, int32_t* h_tri,
+                   double* h_t, double* h_normal, uint64_t* h_visit_hash, int32_t* h_counts,
+                   uint8_t* h_bitmap, int32_t bitmap_stride);
+
+/* Camera rays through ((i + jx)/w, (j + jy)/h) for every pixel (index i + j*w), generated on the
+ * GPU by the render path's camera code; h_origin/h_dir: width*height*3 doubles.
+ * Observes GPU::Camera::rayThrough (reference: src/gpu/GPUCamera.cu:22-32). */
+int cpt_camera_rays(cpt_ctx* ctx, int32_t width, int32_t height, double jx, double jy, double* h_origin,
+                    double* h_dir);
+
+/* Radiance of individual paths (i, j, sample) -> h_radiance n*3 doubles, computed by the same
+ * device functions as cpt_render.  Observes pathTraceRayGPU (reference: src/path_tracer.cu:255-400). */
+int cpt_path_radiance(cpt_ctx* ctx, const cpt_render_params* params, int32_t n, const int32_t* h_ijs,
+                      double* h_radiance);
+
+/* Device-side checks of the arithmetic the parity claims rest on: n doubles in, per element
+ * sqrt(x) and 1/x and a/b as the device computes them (h_b nullable -> b = 3). */
+int cpt_probe_math(cpt_ctx* ctx, int32_t n, const double* h_a, const double* h_b, double* h_sqrt,
+                   double* h_div);
+
+/* Philox-4x32-10 block and its (0,1] double, as the device computes them (known-answer hook). */
+int cpt_probe_rng(cpt_ctx* ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], double out_u01[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPT_AMD_H */
