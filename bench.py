@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|dragon|cornell2]
+
+A step renders the whole workload once (all samples of every pixel of every scene in it) with the
+wavefront pipeline, scenes already resident in HBM.  With N > 1 (launched under torch.distributed.run,
+one rank per GPU) every rank renders its own, disjoint range of sample indices of the same image
+(weak scaling: per-GPU work fixed) and the per-rank radiance sums are reduced to rank 0 over RCCL.
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "cfg2": dict(desc="cornell-box2-specular + cornell-box2-transmissive, 512x512, 256 spp, depth 8",
+                 scenes=["cornell-box2-specular", "cornell-box2-transmissive"], width=512, spp=256, depth=8),
+    # BASELINE.json configs[2]
+    "dragon": dict(desc="dragon-spec, 1024x1024, 1024 spp, depth 8", scenes=["dragon-spec"], width=1024, spp=1024,
+                   depth=8),
+    # BASELINE.json configs[0] shape on the GPU
+    "cornell2": dict(desc="cornell-box2, 512x512, 16 spp, depth 5", scenes=["cornell-box2"], width=512, spp=16,
+                     depth=5),
+}
+
+
+def scene_file(name):
+    return os.path.join(ROOT, "tests", "golden", "scenes", name + ".ray")
+
+
+def extend_bytes(st):
+    """Algorithmic bytes the extend kernel moves: per expanded node one 104-byte record (two child
+    boxes + two child references), per triangle test one 100-byte record (three vertices, unit
+    normal, material/flags), per segment the ray it reads (origin + direction, 48 bytes) and the hit
+    record it writes (t + triangle id + padding, 16 bytes)."""
+    return 104 * st["node_steps"] + 100 * st["tri_tests"] + (48 + 16) * st["segments"]
+
+
+def pipeline_bytes(st):
+    """Algorithmic bytes of the whole path: node and triangle records as above, plus per hit the
+    shading inputs (vertex normals 72 + material 136), per segment the path state written once and
+    read once (88 x 2) and the hit record written and read (16 x 2), per path the 24-byte
+    accumulation update."""
+    return (104 * st["node_steps"] + 100 * st["tri_tests"] + 208 * st["hits"] + (176 + 32) * st["segments"]
+            + 24 * st["paths"])
+
+
+def cpu_baseline(workload, seconds_target=12.0):
+    """The reference's CPU path tracer (oracle restatement), timed on this box's host cores on a
+    bounded sample of the same workload: a 64x64-pixel render of each scene at the workload's depth."""
+    from oracle import pyoracle
+    threads = min(os.cpu_count() or 1, 16)
+    paths = 0
+    secs = 0.0
+    w = 64
+    spp = 1
+    for name in workload["scenes"]:
+        sc = pyoracle.OracleScene(scene_file(name))
+        per_scene = seconds_target / len(workload["scenes"])
+        t_scene = 0.0
+        n_scene = 0
+        while t_scene < per_scene and spp <= 65536:
+            _, _, s = sc.render_cpu_reference(w, w, spp, workload["depth"], threads)
+            t_scene += s
+            n_scene += w * w * spp
+            if s < per_scene / 3:
+                spp *= 2
+        paths += n_scene
+        secs += t_scene
+    return {"value": paths / secs / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
+            "sample": "oracle restatement of the reference CPU path tracer (branching estimator, recursive BVH walk), "
+                      "64x64 px of each scene at depth %d, %d paths in %.1f s" % (workload["depth"], paths, secs)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="wavefront", choices=["wavefront", "mega"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-paths", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from cuda_path_tracer_amd import MODE_MEGAKERNEL, MODE_WAVEFRONT, HostScene, Renderer
+    from cuda_path_tracer_amd.dist import reduce_radiance
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = WORKLOADS[args.workload]
+    mode = MODE_WAVEFRONT if args.mode == "wavefront" else MODE_MEGAKERNEL
+    stream = torch.cuda.current_stream()
+    renderers = []
+    for name in wl["scenes"]:
+        hs = HostScene(scene_file(name))
+        r = Renderer(local_rank)
+        r.set_stream(stream.cuda_stream)
+        if args.batch_paths:
+            r.set_option("batch_paths", args.batch_paths)
+        r.upload(hs)
+        w = wl["width"]
+        h = hs.height_for_width(w)
+        acc = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+        rgb = torch.zeros(h, w, 3, dtype=torch.uint8, device="cuda")
+        renderers.append((r, hs, w, h, acc, rgb))
+    spp = wl["spp"]
+    s0, s1 = rank * spp, (rank + 1) * spp  # weak scaling: every rank adds `spp` new sample indices
+
+    def step():
+        for (r, hs, w, h, acc, rgb) in renderers:
+            acc.zero_()
+            r.render_into(acc.data_ptr(), r.params(w, h, s0, s1, wl["depth"], mode=mode))
+            reduce_radiance(acc, dst=0)
+            if rank == 0:
+                r.tonemap_into(acc.data_ptr(), w, h, spp * world, rgb.data_ptr())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    paths_per_step_per_gpu = sum(w * h * spp for (_, _, w, h, _, _) in renderers)
+    value = world * args.steps * paths_per_step_per_gpu / elapsed / 1e6
+
+    out = None
+    if rank == 0:
+        # one instrumented step for per-kernel HIP-event time, one counting step for the work done
+        roof = None
+        for (r, *_rest) in renderers:
+            r.reset_stats()
+            r.set_instrumentation(time_kernels=True, count_work=False)
+        step()
+        torch.cuda.synchronize()
+        timed = [r.stats() for (r, *_rest) in renderers]
+        for (r, *_rest) in renderers:
+            r.reset_stats()
+            r.set_instrumentation(time_kernels=False, count_work=True)
+        step()
+        torch.cuda.synchronize()
+        counted = [r.stats() for (r, *_rest) in renderers]
+        for (r, *_rest) in renderers:
+            r.set_instrumentation(False, False)
+        agg = {k: sum(c[k] for c in counted) for k in ("paths", "segments", "hits", "node_steps", "tri_tests")}
+        if mode == MODE_WAVEFRONT:
+            ms = sum(t["ms_extend"] for t in timed)
+            launches = sum(t["launches_extend"] for t in timed)
+            kernel, kbytes = "k_extend", extend_bytes(agg)
+        else:
+            ms = sum(t["ms_mega"] for t in timed)
+            launches = sum(t["launches_mega"] for t in timed)
+            kernel, kbytes = "k_megakernel", pipeline_bytes(agg)
+        achieved = kbytes / (ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.workload, {}).get(kernel)
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "bytes_per_launch": kbytes / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
+                "launches_per_step": launches,
+                "pipeline_GBps": pipeline_bytes(agg) / (sum(t["ms_total"] for t in timed) * 1e-3) / 1e9,
+                "per_segment": {"node_steps": agg["node_steps"] / max(agg["segments"], 1),
+                                "tri_tests": agg["tri_tests"] / max(agg["segments"], 1),
+                                "segments_per_path": agg["segments"] / max(agg["paths"], 1)},
+                "kernel_ms_per_step": {k: sum(t[k] for t in timed) for k in
+                                       ("ms_generate", "ms_extend", "ms_shade", "ms_mega", "ms_total")}}
+        out = {"metric": "Mpaths/s", "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": wl["desc"], "mode": args.mode, "paths_per_step": world * paths_per_step_per_gpu,
+                          "sharding": "spp range per rank, fp64 radiance reduce to rank 0" if world > 1 else "single GPU"},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

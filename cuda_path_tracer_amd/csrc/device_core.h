@@ -60,6 +60,37 @@ __device__ __forceinline__ bool slab_hit(double lx, double ly, double lz, double
     return ok;
 }
 
+// The same verdict as slab_hit, usually without dividing.  With r = 1/d rounded once per ray,
+// a = (plane - o) * r differs from the reference's rounded quotient t = (plane - o) / d by at most
+// 3.1 ulp of a.  The reference's verdict is "every axis' near t <= every axis' far t, and the
+// smallest far t >= 1e-12"; on one axis near <= far always holds (rounding is monotonic), so only
+// the six cross-axis orderings and the epsilon test decide.  When every one of those comparisons
+// is further from equality than the error bound, the verdict computed from the products is the
+// reference's verdict; otherwise `sure` is false and the caller redoes the box with slab_hit.
+// Subnormal, infinite or NaN intermediates end up as "not sure"; the caller must not use this test
+// at all for a ray with a zero direction component (the reference skips such an axis).
+__device__ __forceinline__ bool slab_filtered(double lx, double ly, double lz, double hx, double hy, double hz,
+                                              const dvec3& o, const dvec3& r, bool& sure) {
+    double x1 = (lx - o.x) * r.x, x2 = (hx - o.x) * r.x;
+    double y1 = (ly - o.y) * r.y, y2 = (hy - o.y) * r.y;
+    double z1 = (lz - o.z) * r.z, z2 = (hz - o.z) * r.z;
+    double nx = fmin(x1, x2), fx = fmax(x1, x2);
+    double ny = fmin(y1, y2), fy = fmax(y1, y2);
+    double nz = fmin(z1, z2), fz = fmax(z1, z2);
+    double cx = fmax(ny, nz), cy = fmax(nx, nz), cz = fmax(nx, ny);  // largest near t of the other two axes
+    double gx = fx - cx, gy = fy - cy, gz = fz - cz;
+    const double k = 1e-15, tiny = 1e-300;  // 9 ulp relative, plus an absolute floor for the subnormal range
+    double mx = (fabs(fx) + fabs(cx)) * k + tiny, my = (fabs(fy) + fabs(cy)) * k + tiny, mz = (fabs(fz) + fabs(cz)) * k + tiny;
+    double far_min = fmin(fx, fmin(fy, fz));
+    bool order_yes = (gx > mx) && (gy > my) && (gz > mz);
+    bool order_no = (gx < -mx) || (gy < -my) || (gz < -mz);
+    bool eps_yes = far_min > 1.000000000000001e-12;
+    bool eps_no = far_min < 0.999999999999999e-12;
+    bool hit = order_yes && eps_yes;
+    sure = hit || order_no || eps_no;
+    return hit;
+}
+
 // Ray/triangle test (reference: src/gpu/GPUTrimesh.cuh:59-113): plane hit, back-face cull unless
 // the material is reflective/transmissive, t >= 0, three edge tests.  Returns t through t_out.
 __device__ __forceinline__ bool tri_hit(const cpt_tri* __restrict__ tp, const dvec3& o, const dvec3& d,
@@ -110,12 +141,21 @@ __device__ __forceinline__ void traverse(const DScene& sc, const dvec3& o, const
     }
     int sp = 0;
     int node = 0;
+    const dvec3 rinv = dv(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    // A zero direction component makes the reference skip that axis altogether, which the products
+    // cannot express (the reciprocal is infinite): such rays always take the exact test.
+    const bool exact_only = !(fabs(rinv.x) < 1e300 && fabs(rinv.y) < 1e300 && fabs(rinv.z) < 1e300);
     for (;;) {
         const double2* p = (const double2*)(sc.nodes + node);
         double2 b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3], b4 = p[4], b5 = p[5];
         int4 refs = ((const int4*)p)[6];  // lref, rref, lid, rid
-        bool hl = slab_hit(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, o, d);
-        bool hr = slab_hit(b3.x, b3.y, b4.x, b4.y, b5.x, b5.y, o, d);
+        bool sure_l, sure_r;
+        bool hl = slab_filtered(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, o, rinv, sure_l);
+        bool hr = slab_filtered(b3.x, b3.y, b4.x, b4.y, b5.x, b5.y, o, rinv, sure_r);
+        if (exact_only || !(sure_l && sure_r)) {  // rare: a comparison too close to call without the exact quotients
+            hl = slab_hit(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, o, d);
+            hr = slab_hit(b3.x, b3.y, b4.x, b4.y, b5.x, b5.y, o, d);
+        }
         if (TRACE) {
             rec->node_steps++;
             rec->box_tests += 2;

@@ -1,0 +1,27 @@
+"""Multi-GPU sharding of one render: one process per GPU, samples-per-pixel split across ranks,
+per-rank radiance sums combined with one reduce (RCCL over xGMI when the tensors are on GPUs).
+
+The reference is single-GPU; this has no counterpart there.  Because every random number is
+addressed by (pixel, sample, bounce), rank r rendering samples [b_r, e_r) produces exactly the
+paths a single GPU would have produced for those sample indices: the image does not depend on the
+number of GPUs except for the order of the final fp64 additions.
+"""
+
+
+def sample_range(rank, world, first, count):
+    """Contiguous share of sample indices [first, first+count) for `rank` of `world`: the first
+    count % world ranks get one extra sample."""
+    if world < 1 or not (0 <= rank < world) or count < 0:
+        raise ValueError("bad rank/world/count")
+    base, extra = divmod(count, world)
+    begin = first + rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def reduce_radiance(accum, dst=0, group=None):
+    """Sum every rank's accumulation tensor into rank `dst` (in place there).  One collective of
+    w*h*3 float64 per render."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return accum
