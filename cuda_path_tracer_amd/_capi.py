@@ -28,7 +28,7 @@ class Node(C.Structure):
 
 class Tri(C.Structure):
     _fields_ = [("a", C.c_double * 3), ("b", C.c_double * 3), ("c", C.c_double * 3), ("n", C.c_double * 3),
-                ("material", C.c_int32), ("flags", C.c_uint32), ("pad_", C.c_int32 * 6)]
+                ("material", C.c_int32), ("flags", C.c_uint32), ("test_rank", C.c_uint32), ("pad_", C.c_int32 * 5)]
 
 
 class TriNormals(C.Structure):

@@ -35,8 +35,10 @@ struct cpt_ctx {
     size_t path_capacity = 0;
     PathArrays A{};
     uint32_t* d_queue[2] = {nullptr, nullptr};
-    uint32_t* d_counters = nullptr;        // CPT_MAX_DEPTH + 2 queue lengths
+    uint32_t* d_counters = nullptr;        // CPT_MAX_DEPTH + 2 queue lengths, then as many queue cursors
     unsigned long long* d_work = nullptr;  // paths, segments, hits, node steps, triangle tests
+    uint32_t* d_spill = nullptr;           // stack overflow columns of the persistent-wave extend kernel
+    int spill_blocks = 0;
 
     bool time_kernels = false, count_work = false;
     cpt_stats stats{};
@@ -44,6 +46,9 @@ struct cpt_ctx {
 
     int max_blocks = 0;            // grid cap of the grid-stride kernels
     long long batch_paths = 1 << 21;  // path slots kept in flight by the wavefront pipeline
+    int pw_blocks = 0;             // persistent workgroups of the extend kernel (one per CU)
+    int pw_chunk = 256;            // queue entries a persistent wave takes per atomic
+    int extend_variant = 1;        // 0: one ray per thread; 1: persistent waves with refill
 };
 
 static thread_local std::string g_create_error;
@@ -96,10 +101,11 @@ int cpt_create(int device, cpt_ctx** out) {
     hipError_t e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) { delete c; return fail(nullptr, CPT_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
     c->max_blocks = prop.multiProcessorCount * 8;
+    c->pw_blocks = prop.multiProcessorCount;
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(nullptr, CPT_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
-    e = hipMalloc((void**)&c->d_counters, (CPT_MAX_DEPTH + 2) * sizeof(uint32_t));
+    e = hipMalloc((void**)&c->d_counters, 2 * (CPT_MAX_DEPTH + 2) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_work, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->d_work, 0, 8 * sizeof(unsigned long long));
     if (e != hipSuccess) { cpt_destroy(c); return fail(nullptr, CPT_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
@@ -115,6 +121,7 @@ void cpt_destroy(cpt_ctx* c) {
     free_paths(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_work) (void)hipFree(c->d_work);
+    if (c->d_spill) (void)hipFree(c->d_spill);
     for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -143,6 +150,15 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
     } else if (!strcmp(key, "max_blocks")) {
         if (value < 1) return fail(c, CPT_EINVAL, "max_blocks must be >= 1");
         c->max_blocks = (int)value;
+    } else if (!strcmp(key, "pw_blocks")) {
+        if (value < 1) return fail(c, CPT_EINVAL, "pw_blocks must be >= 1");
+        c->pw_blocks = (int)value;
+    } else if (!strcmp(key, "pw_chunk")) {
+        if (value < 1 || value > (1 << 20)) return fail(c, CPT_EINVAL, "pw_chunk must be in [1, 2^20]");
+        c->pw_chunk = (int)value;
+    } else if (!strcmp(key, "extend_variant")) {
+        if (value != 0 && value != 1) return fail(c, CPT_EINVAL, "extend_variant must be 0 or 1");
+        c->extend_variant = (int)value;
     } else {
         return fail(c, CPT_EINVAL, "unknown option '%s'", key);
     }
@@ -194,7 +210,27 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     HIP_TRY(c, hipMalloc(&c->d_tnorm, sizeof(cpt_tri_normals) * (size_t)s->n_tris));
     HIP_TRY(c, hipMalloc(&c->d_mats, sizeof(cpt_material) * (size_t)s->n_materials));
     if (s->n_nodes > 0) HIP_TRY(c, hipMemcpy(c->d_nodes, s->nodes, sizeof(cpt_node) * (size_t)s->n_nodes, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_tris, s->tris, sizeof(cpt_tri) * (size_t)s->n_tris, hipMemcpyHostToDevice));
+    {   // The tie-break rank of a triangle is the position of its leaf's box test in the reference's
+        // traversal order: 2 * (expansion order of the parent) + side, where nodes are expanded in
+        // depth-first, left-first order.  Derived here from the node table, whatever order the records
+        // are stored in.
+        std::vector<cpt_tri> tris(s->tris, s->tris + s->n_tris);
+        for (cpt_tri& t : tris) t.test_rank = 0;
+        std::vector<int> todo;
+        if (s->n_nodes > 0) todo.push_back(0);
+        uint32_t order = 0;
+        while (!todo.empty()) {
+            int k = todo.back();
+            todo.pop_back();
+            const cpt_node& nd = s->nodes[k];
+            if (nd.lref < 0) tris[(size_t)(~nd.lref)].test_rank = 2u * order;
+            if (nd.rref < 0) tris[(size_t)(~nd.rref)].test_rank = 2u * order + 1u;
+            if (nd.rref >= 0) todo.push_back(nd.rref);
+            if (nd.lref >= 0) todo.push_back(nd.lref);
+            ++order;
+        }
+        HIP_TRY(c, hipMemcpy(c->d_tris, tris.data(), sizeof(cpt_tri) * (size_t)s->n_tris, hipMemcpyHostToDevice));
+    }
     HIP_TRY(c, hipMemcpy(c->d_tnorm, s->tri_normals, sizeof(cpt_tri_normals) * (size_t)s->n_tris, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_mats, s->materials, sizeof(cpt_material) * (size_t)s->n_materials, hipMemcpyHostToDevice));
     c->sc.nodes = (const cpt_node*)c->d_nodes;
@@ -270,7 +306,7 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
     if (rc != CPT_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     if (P.s1 == P.s0) return CPT_OK;
-    LaunchCfg L{c->stream, c->max_blocks};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk};
     unsigned long long* work = c->count_work ? c->d_work : nullptr;
     const bool timed = c->time_kernels;
     long long n_paths = (long long)P.w * P.h * (P.s1 - P.s0);
@@ -294,6 +330,13 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
     }
 
     // wavefront: batches of whole samples
+    if (c->extend_variant == 1 && c->spill_blocks < c->pw_blocks) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->d_spill) (void)hipFree(c->d_spill);
+        c->d_spill = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&c->d_spill, (size_t)(CPT_PW_STACK_MAX - CPT_PW_STACK_LDS_HOST) * (size_t)c->pw_blocks * CPT_PW_THREADS_HOST * sizeof(uint32_t)));
+        c->spill_blocks = c->pw_blocks;
+    }
     long long per_sample = P.n_pix_slots;
     int batch = (int)std::max(1ll, std::min((long long)(P.s1 - P.s0), c->batch_paths / per_sample));
     rc = ensure_paths(c, (size_t)batch * (size_t)per_sample);
@@ -304,12 +347,15 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
         int bn = std::min(batch, P.s1 - bs);
         long long slots = (long long)bn * per_sample;
         size_t ev = 0;
+        uint32_t* cursors = c->d_counters + (CPT_MAX_DEPTH + 2);
         HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, (size_t)(P.depth + 2) * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(cursors, 0, (size_t)(P.depth + 2) * sizeof(uint32_t), c->stream));
         if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
         launch_generate(L, c->sc, P, c->A, bs, bn, c->d_queue[0], c->d_counters);
         if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
         for (int b = 0; b <= P.depth; ++b) {
-            launch_extend(L, c->sc, c->A, c->d_queue[b & 1], c->d_counters + b, slots, work);
+            if (c->extend_variant == 1) launch_extend_pw(L, c->sc, c->A, c->d_queue[b & 1], c->d_counters + b, cursors + b, c->d_spill, slots, work);
+            else launch_extend(L, c->sc, c->A, c->d_queue[b & 1], c->d_counters + b, slots, work);
             if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
             launch_shade(L, c->sc, P, c->A, bs, b, c->d_queue[b & 1], c->d_counters + b, c->d_queue[(b + 1) & 1],
                          c->d_counters + b + 1, slots, work);
@@ -346,7 +392,7 @@ int cpt_tonemap(cpt_ctx* c, const double* d_accum, int32_t w, int32_t h, int32_t
     if (!c || !d_accum || !d_rgb) return c ? fail(c, CPT_EINVAL, "cpt_tonemap: NULL argument") : CPT_EINVAL;
     if (w < 1 || h < 1 || total_spp < 1) return fail(c, CPT_EINVAL, "cpt_tonemap: bad size or sample count");
     HIP_TRY(c, hipSetDevice(c->device));
-    LaunchCfg L{c->stream, c->max_blocks};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk};
     launch_tonemap(L, d_accum, w * h * 3, total_spp, d_rgb);
     HIP_TRY(c, hipGetLastError());
     return CPT_OK;
@@ -418,7 +464,7 @@ int cpt_trace_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, 
     if (h_bitmap) { HIP_TRY(c, bm.alloc(N * (size_t)stride)); HIP_TRY(c, hipMemsetAsync(bm.p, 0, N * (size_t)stride, c->stream)); }
     HIP_TRY(c, hipMemcpyAsync(o.p, h_o, N * 24, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d.p, h_d, N * 24, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk};
     launch_trace_rays(L, c->sc, n, (const double*)o.p, (const double*)d.p, (int*)tri.p, (double*)t.p, (double*)nrm.p,
                       (unsigned long long*)vh.p, (int*)cnt.p, h_bitmap ? (uint8_t*)bm.p : nullptr, stride);
     HIP_TRY(c, hipGetLastError());
@@ -439,7 +485,7 @@ int cpt_camera_rays(cpt_ctx* c, int32_t w, int32_t h, double jx, double jy, doub
     size_t N = (size_t)w * h;
     DevBuf o, d;
     HIP_TRY(c, o.alloc(N * 24)); HIP_TRY(c, d.alloc(N * 24));
-    LaunchCfg L{c->stream, c->max_blocks};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk};
     launch_camera_rays(L, c->sc, w, h, jx, jy, (double*)o.p, (double*)d.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_o, o.p, N * 24, hipMemcpyDeviceToHost, c->stream));
@@ -463,7 +509,7 @@ int cpt_path_radiance(cpt_ctx* c, const cpt_render_params* p, int32_t n, const i
     size_t N = (size_t)n;
     HIP_TRY(c, ij.alloc(N * 12)); HIP_TRY(c, rad.alloc(N * 24));
     HIP_TRY(c, hipMemcpyAsync(ij.p, h_ijs, N * 12, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk};
     launch_path_radiance(L, c->sc, P, n, (const int*)ij.p, (double*)rad.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_rad, rad.p, N * 24, hipMemcpyDeviceToHost, c->stream));
@@ -480,7 +526,7 @@ int cpt_probe_math(cpt_ctx* c, int32_t n, const double* h_a, const double* h_b, 
     HIP_TRY(c, a.alloc(N * 8)); HIP_TRY(c, b.alloc(N * 8)); HIP_TRY(c, s.alloc(N * 8)); HIP_TRY(c, q.alloc(N * 8));
     HIP_TRY(c, hipMemcpyAsync(a.p, h_a, N * 8, hipMemcpyHostToDevice, c->stream));
     if (h_b) HIP_TRY(c, hipMemcpyAsync(b.p, h_b, N * 8, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk};
     launch_probe_math(L, n, (const double*)a.p, h_b ? (const double*)b.p : nullptr, (double*)s.p, (double*)q.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_sqrt, s.p, N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -494,7 +540,7 @@ int cpt_probe_rng(cpt_ctx* c, const uint32_t ctr[4], const uint32_t key[2], uint
     HIP_TRY(c, hipSetDevice(c->device));
     DevBuf o, u;
     HIP_TRY(c, o.alloc(16)); HIP_TRY(c, u.alloc(16));
-    LaunchCfg L{c->stream, c->max_blocks};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk};
     launch_probe_rng(L, ctr, key, (uint32_t*)o.p, (double*)u.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, o.p, 16, hipMemcpyDeviceToHost, c->stream));

@@ -93,13 +93,10 @@ __device__ __forceinline__ bool slab_filtered(double lx, double ly, double lz, d
 
 // Ray/triangle test (reference: src/gpu/GPUTrimesh.cuh:59-113): plane hit, back-face cull unless
 // the material is reflective/transmissive, t >= 0, three edge tests.  Returns t through t_out.
-__device__ __forceinline__ bool tri_hit(const cpt_tri* __restrict__ tp, const dvec3& o, const dvec3& d,
-                                        double& t_out) {
-    const double2* q = (const double2*)tp;  // 128-byte aligned record: a, b, c, n, material, flags
-    double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
-    uint2 mf = ((const uint2*)tp)[12];
+__device__ __forceinline__ bool tri_hit_regs(double2 q0, double2 q1, double2 q2, double2 q3, double2 q4, double2 q5,
+                                             uint32_t flags, const dvec3& o, const dvec3& d, double& t_out) {
     dvec3 a = dv(q0.x, q0.y, q1.x), b = dv(q1.y, q2.x, q2.y), c = dv(q3.x, q3.y, q4.x), n = dv(q4.y, q5.x, q5.y);
-    bool recur = (mf.y & CPT_TRI_RECUR) != 0;
+    bool recur = (flags & CPT_TRI_RECUR) != 0;
     double numerator = -dot(o - a, n);
     double denominator = dot(d, n);
     if (denominator >= 0) {
@@ -114,14 +111,22 @@ __device__ __forceinline__ bool tri_hit(const cpt_tri* __restrict__ tp, const dv
     t_out = t;
     return res;
 }
+__device__ __forceinline__ bool tri_hit(const cpt_tri* __restrict__ tp, const dvec3& o, const dvec3& d,
+                                        double& t_out) {
+    const double2* q = (const double2*)tp;  // 128-byte aligned record: a, b, c, n, material, flags
+    double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+    uint2 mf = ((const uint2*)tp)[12];
+    return tri_hit_regs(q0, q1, q2, q3, q4, q5, mf.y, o, d, t_out);
+}
 
 // Closest hit over the scene, visiting exactly the nodes the reference's stack traversal visits
 // (reference: src/gpu/GPUBVH.cu:38-99): both child boxes of every expanded node are tested, leaf
 // children are intersected, the left child is descended and the right one postponed.  There is
 // no near/far ordering and no culling by the current closest hit, so the set of tested nodes is a
 // property of the ray alone.  On equal t the reference keeps the leaf it tested first; its test
-// order is (expansion order of the parent, left before right), and records are stored in
-// expansion order, so the rule is "smaller 2*record + side wins" whatever order we walk in.
+// order is (expansion order of the parent, left before right), a total order that does not depend
+// on the ray; every triangle record carries that position as test_rank, so the rule is "smaller
+// test_rank wins" whatever order we walk in.
 //
 // `stack` points at this lane's column of an LDS array laid out [entry][lane]: entry e of lane l
 // lives at stack[e * CPT_WAVE], which puts the 64 lanes of a wave on distinct banks.
@@ -169,7 +174,7 @@ __device__ __forceinline__ void traverse(const DScene& sc, const dvec3& o, const
             double t;
             if (TRACE) rec->tri_tests++;
             if (tri_hit(sc.tris + (~refs.x), o, d, t)) {
-                uint32_t rank = 2u * (uint32_t)node;
+                uint32_t rank = sc.tris[~refs.x].test_rank;
                 if (best_t < 0 || t < best_t || (t == best_t && rank < best_rank)) { best_t = t; best_tri = ~refs.x; best_rank = rank; }
             }
         }
@@ -177,7 +182,7 @@ __device__ __forceinline__ void traverse(const DScene& sc, const dvec3& o, const
             double t;
             if (TRACE) rec->tri_tests++;
             if (tri_hit(sc.tris + (~refs.y), o, d, t)) {
-                uint32_t rank = 2u * (uint32_t)node + 1u;
+                uint32_t rank = sc.tris[~refs.y].test_rank;
                 if (best_t < 0 || t < best_t || (t == best_t && rank < best_rank)) { best_t = t; best_tri = ~refs.y; best_rank = rank; }
             }
         }

@@ -111,6 +111,201 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, PathArrays A, c
     }
 }
 
+// ---- extend, persistent waves ------------------------------------------------------------------
+// One 1024-thread workgroup per CU; each of its 16 waves keeps 64 rays in flight and refills
+// finished lanes from the queue, so a wave is not held up by its longest traversal.  Work per ray
+// is a fixed set of node expansions and triangle tests (the reference never orders or culls), so
+// their order is free: leaf hits are parked on a second per-lane LDS stack and tested when enough
+// lanes have one, which keeps both the box code and the triangle code running with most lanes
+// active instead of alternating half-empty.
+//
+// Incoherent rays make every lane fetch a different 128-byte record, and then the vector memory
+// path, not arithmetic, bounds the kernel.  The workgroup therefore keeps the head of the node
+// array (records are stored top of the tree first) and the head of the triangle array in LDS, 64 KB
+// shared by its 16 waves: small scenes live there entirely, large ones keep their upper levels
+// there.  A cached record's eight 16-byte pieces are stored rotated by an XOR with (r >> 1) & 7 so
+// that lanes reading the same piece of different records spread over the LDS banks.
+//
+// Queue entries are claimed in chunks: one atomic per `chunk` rays, the rest is wave-local.
+// The per-lane node stack keeps its first CPT_PW_STACK_LDS entries in LDS; deeper entries (rare)
+// go to a per-lane column of `spill` in global memory.
+#define CPT_PW_THREADS 1024
+#define CPT_PW_WAVES (CPT_PW_THREADS / CPT_WAVE)
+#define CPT_PW_CACHE_RECORDS 512  // 64 KB of 128-byte records
+#define CPT_PW_STACK_LDS 16
+static_assert(CPT_PW_STACK_LDS == CPT_PW_STACK_LDS_HOST, "stack split must match the spill buffer sizing");
+#define CPT_PW_LEAF_CAP 6     // parked leaves per lane (a node expansion adds at most two)
+#define CPT_PW_REFILL 12      // refill when at least this many lanes are idle
+#define CPT_PW_LEAF_GO 20     // run the triangle phase when at least this many lanes have a parked leaf
+
+struct Rec7 {  // the first seven 16-byte pieces of a 128-byte record
+    double2 p0, p1, p2, p3, p4, p5, p6;
+};
+__device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, const unsigned char* cache, int cache_first,
+                                             int cached, int idx) {
+    Rec7 r;
+    if (idx < cached) {
+        const unsigned char* rec = cache + (size_t)(cache_first + idx) * 128;
+        const uint32_t z = ((uint32_t)(cache_first + idx) >> 1) & 7u;
+        r.p0 = *(const double2*)(rec + ((0u ^ z) << 4)); r.p1 = *(const double2*)(rec + ((1u ^ z) << 4));
+        r.p2 = *(const double2*)(rec + ((2u ^ z) << 4)); r.p3 = *(const double2*)(rec + ((3u ^ z) << 4));
+        r.p4 = *(const double2*)(rec + ((4u ^ z) << 4)); r.p5 = *(const double2*)(rec + ((5u ^ z) << 4));
+        r.p6 = *(const double2*)(rec + ((6u ^ z) << 4));
+    } else {
+        const double2* g = (const double2*)((const unsigned char*)base + (size_t)idx * 128);
+        r.p0 = g[0]; r.p1 = g[1]; r.p2 = g[2]; r.p3 = g[3]; r.p4 = g[4]; r.p5 = g[5]; r.p6 = g[6];
+    }
+    return r;
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, PathArrays A, const uint32_t* __restrict__ queue,
+                                                              const uint32_t* __restrict__ counter, uint32_t* cursor,
+                                                              uint32_t chunk, uint32_t* spill, unsigned long long* work) {
+    __shared__ __attribute__((aligned(128))) unsigned char s_cache[CPT_PW_CACHE_RECORDS * 128];
+    __shared__ uint32_t s_nodes[CPT_PW_WAVES][CPT_PW_STACK_LDS][CPT_WAVE];
+    __shared__ uint32_t s_leaves[CPT_PW_WAVES][CPT_PW_LEAF_CAP][CPT_WAVE];
+    const uint32_t lane = threadIdx.x & (CPT_WAVE - 1), wave = threadIdx.x / CPT_WAVE;
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+    const uint32_t n = *counter;
+
+    // fill the record cache: node records first, triangle records in what is left
+    const int cached_nodes = sc.n_nodes < CPT_PW_CACHE_RECORDS ? sc.n_nodes : CPT_PW_CACHE_RECORDS;
+    const int room = CPT_PW_CACHE_RECORDS - cached_nodes;
+    const int cached_tris = sc.n_tris < room ? sc.n_tris : room;
+    for (int i = (int)threadIdx.x; i < (cached_nodes + cached_tris) * 8; i += CPT_PW_THREADS) {
+        int r = i >> 3, c = i & 7;
+        const unsigned char* src = r < cached_nodes ? (const unsigned char*)sc.nodes + (size_t)r * 128
+                                                    : (const unsigned char*)sc.tris + (size_t)(r - cached_nodes) * 128;
+        *(double2*)(s_cache + (size_t)r * 128 + (((uint32_t)c ^ (((uint32_t)r >> 1) & 7u)) << 4)) = *(const double2*)(src + c * 16);
+    }
+    __syncthreads();
+
+    uint32_t* my_nodes = &s_nodes[wave][0][lane];    // entry e at my_nodes[e * CPT_WAVE]
+    uint32_t* my_leaves = &s_leaves[wave][0][lane];
+    uint32_t* my_spill = spill + (size_t)blockIdx.x * CPT_PW_THREADS + threadIdx.x;  // entry e at my_spill[e * spill_stride]
+    const size_t spill_stride = (size_t)gridDim.x * CPT_PW_THREADS;
+    uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform: unclaimed part of this wave's chunk
+    bool drained = false;                   // wave-uniform: the queue has been handed out completely
+
+    bool has_ray = false;
+    int node = -1, sp = 0, lp = 0, slot = 0;
+    dvec3 o = dv(0, 0, 0), d = dv(0, 0, 1), rinv = dv(0, 0, 1);
+    bool exact_only = false;
+    double best_t = -1.0;
+    int best_tri = -1;
+    uint32_t best_rank = 0xFFFFFFFFu;
+    unsigned long long steps = 0, tris = 0;
+
+    for (;;) {
+        // ---- refill idle lanes ----
+        uint64_t idle = __ballot(!has_ray);
+        if (!drained && (uint32_t)__popcll(idle) >= CPT_PW_REFILL) {
+            if (chunk_pos == chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor, chunk);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                chunk_pos = base < n ? base : n;
+                chunk_end = (base + chunk) < n ? (base + chunk) : n;
+                if (chunk_pos == chunk_end) drained = true;
+            }
+            uint32_t avail = chunk_end - chunk_pos;
+            uint32_t want = (uint32_t)__popcll(idle);
+            uint32_t take = want < avail ? want : avail;
+            uint32_t mine = (uint32_t)__popcll(idle & lanes_below);
+            if (!has_ray && mine < take) {
+                slot = (int)queue[chunk_pos + mine];
+                o = dv(A.ox[slot], A.oy[slot], A.oz[slot]);
+                d = dv(A.dx[slot], A.dy[slot], A.dz[slot]);
+                rinv = dv(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+                exact_only = !(fabs(rinv.x) < 1e300 && fabs(rinv.y) < 1e300 && fabs(rinv.z) < 1e300);
+                best_t = -1.0;
+                best_tri = -1;
+                best_rank = 0xFFFFFFFFu;
+                sp = 0;
+                lp = 0;
+                has_ray = true;
+                if (sc.n_nodes > 0) {
+                    node = 0;
+                } else {  // one-triangle scene
+                    node = -1;
+                    my_leaves[0] = 0u;
+                    lp = 1;
+                }
+            }
+            chunk_pos += take;
+        }
+        if (__ballot(has_ray) == 0) {
+            if (drained) break;
+            continue;
+        }
+
+        // ---- box phase: expand one node per lane that has one (and room to park two more leaves) ----
+        if (node >= 0 && lp <= CPT_PW_LEAF_CAP - 2) {
+            Rec7 r = fetch_record(sc.nodes, s_cache, 0, cached_nodes, node);
+            int2 refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));  // lref, rref
+            bool sure_l, sure_r;
+            bool hl = slab_filtered(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, rinv, sure_l);
+            bool hr = slab_filtered(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, rinv, sure_r);
+            if (exact_only || !(sure_l && sure_r)) {
+                hl = slab_hit(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, d);
+                hr = slab_hit(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, d);
+            }
+            if (COUNT) steps++;
+            if (hl && refs.x < 0) { my_leaves[lp * CPT_WAVE] = (uint32_t)(~refs.x); ++lp; }
+            if (hr && refs.y < 0) { my_leaves[lp * CPT_WAVE] = (uint32_t)(~refs.y); ++lp; }
+            bool tl = hl && refs.x >= 0, tr = hr && refs.y >= 0;
+            if (tl) {
+                node = refs.x;
+                if (tr) {
+                    if (sp < CPT_PW_STACK_LDS) my_nodes[sp * CPT_WAVE] = (uint32_t)refs.y;
+                    else my_spill[(size_t)(sp - CPT_PW_STACK_LDS) * spill_stride] = (uint32_t)refs.y;
+                    ++sp;
+                }
+            } else if (tr) {
+                node = refs.y;
+            } else if (sp > 0) {
+                --sp;
+                if (sp < CPT_PW_STACK_LDS) node = (int)my_nodes[sp * CPT_WAVE];
+                else node = (int)my_spill[(size_t)(sp - CPT_PW_STACK_LDS) * spill_stride];
+            } else {
+                node = -1;
+            }
+        }
+
+        // ---- triangle phase: when enough lanes have a parked leaf, or nothing else can run ----
+        uint64_t have_leaf = __ballot(lp > 0);
+        if (have_leaf) {
+            uint64_t have_node = __ballot(node >= 0);
+            uint64_t nearly_full = __ballot(lp > CPT_PW_LEAF_CAP - 2);
+            if ((uint32_t)__popcll(have_leaf) >= CPT_PW_LEAF_GO || have_node == 0 || nearly_full) {
+                if (lp > 0) {
+                    --lp;
+                    int tri = (int)my_leaves[lp * CPT_WAVE];
+                    Rec7 q = fetch_record(sc.tris, s_cache, cached_nodes, cached_tris, tri);
+                    uint32_t flags = (uint32_t)__double2hiint(q.p6.x), rank = (uint32_t)__double2loint(q.p6.y);
+                    double t;
+                    if (COUNT) tris++;
+                    if (tri_hit_regs(q.p0, q.p1, q.p2, q.p3, q.p4, q.p5, flags, o, d, t)) {
+                        if (best_t < 0 || t < best_t || (t == best_t && rank < best_rank)) { best_t = t; best_tri = tri; best_rank = rank; }
+                    }
+                }
+            }
+        }
+
+        // ---- retire ----
+        if (has_ray && node < 0 && lp == 0) {
+            A.hit_t[slot] = best_t;
+            A.hit_tri[slot] = best_tri;
+            has_ray = false;
+        }
+    }
+    if (COUNT) {
+        if (steps) atomicAdd(&work[3], steps);
+        if (tris) atomicAdd(&work[4], tris);
+    }
+}
+
 // ---- shade + compact -------------------------------------------------------------------------
 // reference: the shading half of pathTrace (src/improved_path_tracer.cu:77-215)
 template <bool COUNT>
@@ -319,6 +514,13 @@ void launch_extend(const LaunchCfg& L, const DScene& sc, const PathArrays& A, co
     int g = grid_for(max_entries, L.max_blocks);
     if (work) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, A, queue, counter, work);
     else hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, A, queue, counter, work);
+}
+void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const PathArrays& A, const uint32_t* queue, const uint32_t* counter,
+                      uint32_t* cursor, uint32_t* spill, long long max_entries, unsigned long long* work) {
+    (void)max_entries;
+    int g = L.pw_blocks;
+    if (work) hipLaunchKernelGGL(k_extend_pw<true>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, A, queue, counter, cursor, (uint32_t)L.pw_chunk, spill, work);
+    else hipLaunchKernelGGL(k_extend_pw<false>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, A, queue, counter, cursor, (uint32_t)L.pw_chunk, spill, work);
 }
 void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int bounce,
                   const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* queue_out, uint32_t* counter_out,

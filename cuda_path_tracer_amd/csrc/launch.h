@@ -37,15 +37,24 @@ struct PathArrays {
 #define CPT_PATH_DOUBLES 14  // doubles per slot in PathArrays
 #define CPT_PATH_BYTES (CPT_PATH_DOUBLES * 8 + 4)
 
+// traversal stack of the persistent-wave extend kernel: entries in LDS, and the deepest tree it accepts
+#define CPT_PW_STACK_LDS_HOST 16
+#define CPT_PW_STACK_MAX 62
+#define CPT_PW_THREADS_HOST 1024
+
 struct LaunchCfg {
     hipStream_t stream;
     int max_blocks;  // grid cap for grid-stride kernels
+    int pw_blocks;   // number of persistent 1024-thread workgroups of k_extend_pw (one per CU)
+    int pw_chunk;    // queue entries a wave takes per atomic
 };
 
 void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int batch_n,
                      uint32_t* queue, uint32_t* counter);
 void launch_extend(const LaunchCfg& L, const DScene& sc, const PathArrays& A, const uint32_t* queue, const uint32_t* counter,
                    long long max_entries, unsigned long long* work);
+void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const PathArrays& A, const uint32_t* queue, const uint32_t* counter,
+                      uint32_t* cursor, uint32_t* spill, long long max_entries, unsigned long long* work);
 void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int bounce,
                   const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* queue_out, uint32_t* counter_out,
                   long long max_entries, unsigned long long* work);

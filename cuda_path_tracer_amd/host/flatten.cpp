@@ -22,26 +22,32 @@ cpt_material flat_material(const RayMaterial& m) {
     return o;
 }
 
-// Emit internal-node records in preorder; returns the reference to put in the parent.
-int emit(const Bvh& bvh, int id, std::vector<cpt_node>& out) {
-    const BvhNode& n = bvh.nodes[id];
-    if (n.prim >= 0) return ~n.prim;
-    int k = (int)out.size();
-    out.emplace_back();
-    {
-        cpt_node& r = out[k];
+// Emit internal-node records level by level (top of the tree first), so that a prefix of the array
+// is the part of the tree every ray walks through.  Parents always precede their children.
+void emit_records(const Bvh& bvh, std::vector<cpt_node>& out) {
+    std::vector<int> record_of(bvh.nodes.size(), -1), order;
+    if (bvh.nodes.empty() || bvh.nodes[0].prim >= 0) return;
+    order.push_back(0);
+    for (size_t q = 0; q < order.size(); ++q) {
+        const BvhNode& n = bvh.nodes[order[q]];
+        record_of[order[q]] = (int)q;
+        if (bvh.nodes[n.left].prim < 0) order.push_back(n.left);
+        if (bvh.nodes[n.right].prim < 0) order.push_back(n.right);
+    }
+    for (size_t q = 0; q < order.size(); ++q) record_of[order[q]] = (int)q;
+    out.resize(order.size());
+    for (size_t q = 0; q < order.size(); ++q) {
+        const BvhNode& n = bvh.nodes[order[q]];
+        cpt_node& r = out[q];
         std::memset(&r, 0, sizeof r);
         put_box(r.lbox, bvh.nodes[n.left]);
         put_box(r.rbox, bvh.nodes[n.right]);
+        r.lref = bvh.nodes[n.left].prim >= 0 ? ~bvh.nodes[n.left].prim : record_of[n.left];
+        r.rref = bvh.nodes[n.right].prim >= 0 ? ~bvh.nodes[n.right].prim : record_of[n.right];
         r.lid = n.left;
         r.rid = n.right;
-        r.self_id = id;
+        r.self_id = order[q];
     }
-    int l = emit(bvh, n.left, out);
-    out[k].lref = l;
-    int r = emit(bvh, n.right, out);
-    out[k].rref = r;
-    return k;
 }
 
 }  // namespace
@@ -105,7 +111,7 @@ FlatScene flatten_scene(const RayScene& scene) {
     }
     if (f.tris.empty()) throw std::runtime_error("scene has no polymesh triangles to render");
     f.bvh = build_bvh(bounds);
-    if (f.bvh.nodes[0].prim < 0) emit(f.bvh, 0, f.nodes);
+    emit_records(f.bvh, f.nodes);
     return f;
 }
 

@@ -66,7 +66,7 @@ class HostScene:
 
     def tris(self):
         dt = np.dtype([("a", "f8", 3), ("b", "f8", 3), ("c", "f8", 3), ("n", "f8", 3), ("material", "i4"),
-                       ("flags", "u4"), ("pad", "i4", 6)])
+                       ("flags", "u4"), ("test_rank", "u4"), ("pad", "i4", 5)])
         return self._records(self.desc.tris, self.n_tris, dt)
 
     def tri_normals(self):

@@ -36,8 +36,8 @@ extern "C" {
  * 128-byte aligned = one cache line pair per traversal step.
  * Replaces GPU::BVHNode + GPU::BoundingBox (reference: src/gpu/GPUBVH.cuh:17-27,
  * src/gpu/GPUbb.cuh:10-57), which are 80-byte managed allocations reached by pointer.
- * Records are stored in preorder of the internal nodes, so record k is the k-th node the
- * reference's traversal can expand and (2k, 2k+1) is the test rank of its (left, right) child. */
+ * Record 0 is the root and a child's record always comes after its parent's; the host library
+ * stores them level by level, so a prefix of the array is the top of the tree. */
 typedef struct cpt_node {
     double lbox[6];   /* left child  box: min x,y,z then max x,y,z */
     double rbox[6];   /* right child box                            */
@@ -56,7 +56,10 @@ typedef struct cpt_tri {
     double n[3];             /* unit face normal, normalize(cross(b-a, c-a))  */
     int32_t material;        /* index into the material table                 */
     uint32_t flags;          /* CPT_TRI_*                                     */
-    int32_t pad_[6];
+    uint32_t test_rank;      /* position of this triangle's leaf in the reference's traversal order
+                                (2 * expansion order of the parent + side), used to break ties in t.
+                                Filled in by cpt_upload_scene; callers may leave it 0.             */
+    int32_t pad_[5];
 } cpt_tri;
 #define CPT_TRI_RECUR 1u         /* material is reflective or transmissive: no back-face cull */
 #define CPT_TRI_VERTEX_NORMALS 2u /* interpolate cpt_tri_normals instead of the face normal   */

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""One render through the C ABI, for use under rocprofv3 (kernel trace or PMC passes).
+
+    python tools/prof_render.py --scene cornell-box2-transmissive --width 512 --spp 16 --depth 8
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="cornell-box2-transmissive")
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--spp", type=int, default=16)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--mode", type=int, default=0)
+    ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--stats", action="store_true", help="time kernels with HIP events and count work")
+    ap.add_argument("--opt", action="append", default=[], help="key=value passed to cpt_set_option")
+    args = ap.parse_args()
+    import torch
+    from cuda_path_tracer_amd import HostScene, Renderer
+    hs = HostScene(os.path.join(ROOT, "tests", "golden", "scenes", args.scene + ".ray"))
+    r = Renderer(0)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        r.set_option(k, int(v))
+    r.upload(hs)
+    w = args.width
+    h = hs.height_for_width(w)
+    acc = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+    p = r.params(w, h, 0, args.spp, args.depth, mode=args.mode)
+    if args.stats:
+        r.set_instrumentation(time_kernels=True, count_work=False)
+    for _ in range(args.repeat):
+        acc.zero_()
+        r.reset_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r.render_into(acc.data_ptr(), p)
+        r.synchronize()
+        dt = time.perf_counter() - t0
+        print("%s %dx%d spp %d depth %d: %.2f ms, %.1f Mpaths/s, sum %.6f" %
+              (args.scene, w, h, args.spp, args.depth, dt * 1e3, w * h * args.spp / dt / 1e6, float(acc.sum())), flush=True)
+        if args.stats:
+            st = r.stats()
+            print("   ms: generate %.2f extend %.2f shade %.2f total %.2f (launches: %d extend)" %
+                  (st["ms_generate"], st["ms_extend"], st["ms_shade"], st["ms_total"], st["launches_extend"]), flush=True)
+
+
+if __name__ == "__main__":
+    main()
