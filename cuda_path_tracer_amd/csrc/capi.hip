@@ -35,7 +35,9 @@ struct cpt_ctx {
     size_t path_capacity = 0;
     PathArrays A{};
     uint32_t* d_queue[2] = {nullptr, nullptr};
-    uint32_t* d_counters = nullptr;        // CPT_MAX_DEPTH + 2 queue lengths, then as many queue cursors
+    uint32_t* d_lobe_queues = nullptr;     // three queues of path_capacity entries each
+    uint32_t* d_identity = nullptr;        // 0, 1, 2, ...: the queue of every batch's first bounce
+    uint32_t* d_counters = nullptr;        // CPT_MAX_DEPTH + 2 queue lengths, as many queue cursors, 3x as many lobe queue lengths
     unsigned long long* d_work = nullptr;  // paths, segments, hits, node steps, triangle tests
     uint32_t* d_spill = nullptr;           // stack overflow columns of the persistent-wave extend kernel
     int spill_blocks = 0;
@@ -45,10 +47,11 @@ struct cpt_ctx {
     std::vector<hipEvent_t> events;
 
     int max_blocks = 0;            // grid cap of the grid-stride kernels
-    long long batch_paths = 1 << 21;  // path slots kept in flight by the wavefront pipeline
+    long long batch_paths = 1 << 23;  // path slots kept in flight by the wavefront pipeline
     int pw_blocks = 0;             // persistent workgroups of the extend kernel (one per CU)
     int pw_chunk = 256;            // queue entries a persistent wave takes per atomic
     int extend_variant = 1;        // 0: one ray per thread; 1: persistent waves with refill
+    int shade_variant = 0;         // 0: one shade kernel; 1: select + one scatter kernel per lobe (slower: more scattered state traffic)
 };
 
 static thread_local std::string g_create_error;
@@ -81,6 +84,10 @@ static void free_paths(cpt_ctx* c) {
     if (c->d_paths) (void)hipFree(c->d_paths);
     if (c->d_queue[0]) (void)hipFree(c->d_queue[0]);
     if (c->d_queue[1]) (void)hipFree(c->d_queue[1]);
+    if (c->d_lobe_queues) (void)hipFree(c->d_lobe_queues);
+    if (c->d_identity) (void)hipFree(c->d_identity);
+    c->d_lobe_queues = nullptr;
+    c->d_identity = nullptr;
     c->d_paths = nullptr;
     c->d_queue[0] = c->d_queue[1] = nullptr;
     c->path_capacity = 0;
@@ -105,7 +112,7 @@ int cpt_create(int device, cpt_ctx** out) {
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(nullptr, CPT_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
-    e = hipMalloc((void**)&c->d_counters, 2 * (CPT_MAX_DEPTH + 2) * sizeof(uint32_t));
+    e = hipMalloc((void**)&c->d_counters, 5 * (CPT_MAX_DEPTH + 2) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_work, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->d_work, 0, 8 * sizeof(unsigned long long));
     if (e != hipSuccess) { cpt_destroy(c); return fail(nullptr, CPT_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
@@ -156,6 +163,9 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
     } else if (!strcmp(key, "pw_chunk")) {
         if (value < 1 || value > (1 << 20)) return fail(c, CPT_EINVAL, "pw_chunk must be in [1, 2^20]");
         c->pw_chunk = (int)value;
+    } else if (!strcmp(key, "shade_variant")) {
+        if (value != 0 && value != 1) return fail(c, CPT_EINVAL, "shade_variant must be 0 or 1");
+        c->shade_variant = (int)value;
     } else if (!strcmp(key, "extend_variant")) {
         if (value != 0 && value != 1) return fail(c, CPT_EINVAL, "extend_variant must be 0 or 1");
         c->extend_variant = (int)value;
@@ -253,6 +263,13 @@ static int ensure_paths(cpt_ctx* c, size_t slots) {
     HIP_TRY(c, hipMalloc(&c->d_paths, slots * CPT_PATH_BYTES));
     HIP_TRY(c, hipMalloc((void**)&c->d_queue[0], slots * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void**)&c->d_queue[1], slots * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_lobe_queues, 3 * slots * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_identity, slots * sizeof(uint32_t)));
+    {
+        LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk};
+        launch_iota(L, c->d_identity, (long long)slots);
+        HIP_TRY(c, hipGetLastError());
+    }
     double* base = (double*)c->d_paths;
     double** fields[CPT_PATH_DOUBLES] = {&c->A.ox, &c->A.oy, &c->A.oz, &c->A.dx, &c->A.dy, &c->A.dz, &c->A.medium,
                                          &c->A.ax, &c->A.ay, &c->A.az, &c->A.cx, &c->A.cy, &c->A.cz, &c->A.hit_t};
@@ -350,15 +367,27 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
         uint32_t* cursors = c->d_counters + (CPT_MAX_DEPTH + 2);
         HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, (size_t)(P.depth + 2) * sizeof(uint32_t), c->stream));
         HIP_TRY(c, hipMemsetAsync(cursors, 0, (size_t)(P.depth + 2) * sizeof(uint32_t), c->stream));
+        uint32_t* lobe_counters = c->d_counters + 2 * (CPT_MAX_DEPTH + 2);
+        if (c->shade_variant == 1) HIP_TRY(c, hipMemsetAsync(lobe_counters, 0, 3 * (size_t)(P.depth + 2) * sizeof(uint32_t), c->stream));
         if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
-        launch_generate(L, c->sc, P, c->A, bs, bn, c->d_queue[0], c->d_counters);
+        HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_counters, (int)slots, 1, c->stream));
+        launch_generate(L, c->sc, P, c->A, bs, bn);
         if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
         for (int b = 0; b <= P.depth; ++b) {
-            if (c->extend_variant == 1) launch_extend_pw(L, c->sc, c->A, c->d_queue[b & 1], c->d_counters + b, cursors + b, c->d_spill, slots, work);
-            else launch_extend(L, c->sc, c->A, c->d_queue[b & 1], c->d_counters + b, slots, work);
+            const uint32_t* q_in = b == 0 ? c->d_identity : c->d_queue[b & 1];
+            if (c->extend_variant == 1) launch_extend_pw(L, c->sc, c->A, q_in, c->d_counters + b, cursors + b, c->d_spill, slots, work);
+            else launch_extend(L, c->sc, c->A, q_in, c->d_counters + b, slots, work);
             if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
-            launch_shade(L, c->sc, P, c->A, bs, b, c->d_queue[b & 1], c->d_counters + b, c->d_queue[(b + 1) & 1],
-                         c->d_counters + b + 1, slots, work);
+            if (c->shade_variant == 1) {
+                uint32_t* lc = lobe_counters + 3 * b;
+                launch_select(L, c->sc, P, c->A, bs, b, q_in, c->d_counters + b, c->d_lobe_queues, c->path_capacity, lc, slots, work);
+                for (int lobe = 0; lobe < 3; ++lobe)
+                    launch_scatter(L, lobe, c->sc, P, c->A, bs, b, c->d_lobe_queues + (size_t)lobe * c->path_capacity, lc + lobe,
+                                   c->d_queue[(b + 1) & 1], c->d_counters + b + 1, slots);
+            } else {
+                launch_shade(L, c->sc, P, c->A, bs, b, q_in, c->d_counters + b, c->d_queue[(b + 1) & 1],
+                             c->d_counters + b + 1, slots, work);
+            }
             if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
         }
         launch_resolve(L, P, c->A, bn, d_accum);

@@ -321,99 +321,163 @@ __device__ __forceinline__ bool roulette(const DParams& P, uint32_t pixel, uint3
     return true;
 }
 
-// Process the intersection (t, tri) found for s's current ray at bounce `bounce`: add emission,
-// choose a lobe, replace the ray and scale the throughput.  Returns true when the path goes on.
+// One bounce is split in two so the wavefront pipeline can run each half as its own kernel: first
+// the part every hit goes through (emission, termination, lobe choice), then one of three scatter
+// routines.  shade_bounce below chains them for the callers that keep a path in registers, so
+// every path sees the same arithmetic.
 // reference: src/path_tracer.cu:263-397; termination test as src/improved_path_tracer.cu:80.
-__device__ __forceinline__ bool shade_bounce(const DScene& sc, const DParams& P, uint32_t pixel, uint32_t sample,
-                                             int bounce, double t, int tri, PathRegs& s) {
-    if (tri < 0) return false;  // the reference re-intersects the same missing ray until the loop ends
-    const cpt_material* m = sc.mats + sc.tris[tri].material;
-    dvec3 ke = dv(m->ke), kd = dv(m->kd), ks = dv(m->ks), kt = dv(m->kt);
-    s.color = s.color + ke * s.atten;
-    if (!(m->flags & (CPT_MAT_DIFF | CPT_MAT_SPEC | CPT_MAT_TRANS))) return false;
-    if (bounce >= P.depth) return false;  // the new ray would never be traced
-    dvec3 N = shading_normal(sc, tri, s.o, s.d, t);
+#define CPT_LOBE_NONE (-1)
+#define CPT_LOBE_DIFFUSE 0
+#define CPT_LOBE_MIRROR 1
+#define CPT_LOBE_DIELECTRIC 2
+
+struct LobeProb {
+    double diff, spec, trans;
+};
+// reference: src/path_tracer.cu:272-279
+__device__ __forceinline__ LobeProb lobe_probabilities(const cpt_material* m) {
+    dvec3 kd = dv(m->kd), ks = dv(m->ks), kt = dv(m->kt);
     double spec = (ks.x + ks.y + ks.z) / 3.0;
     double diff = (kd.x + kd.y + kd.z) / 3.0;
     double trans = (kt.x + kt.y + kt.z) / 3.0;
     double total = spec + diff + trans;
-    double diffProb = diff / total, specProb = spec / total, transProb = trans / total;
-    double prob, sampleFresnel;
-    draw2(P, pixel, sample, (uint32_t)bounce, CPT_STREAM_SELECT, prob, sampleFresnel);
+    LobeProb p;
+    p.diff = diff / total;
+    p.spec = spec / total;
+    p.trans = trans / total;
+    return p;
+}
+
+// Emission and lobe choice for a hit on triangle `tri` (tri < 0: the ray missed).  Updates `color`
+// with the throughput `atten`; returns the lobe to scatter with, or CPT_LOBE_NONE when the path ends.
+__device__ __forceinline__ int choose_lobe(const DScene& sc, const DParams& P, uint32_t pixel, uint32_t sample, int bounce,
+                                           int tri, const dvec3& atten, dvec3& color) {
+    if (tri < 0) return CPT_LOBE_NONE;  // the reference re-intersects the same missing ray until the loop ends
+    const cpt_material* m = sc.mats + sc.tris[tri].material;
+    color = color + dv(m->ke) * atten;
+    if (!(m->flags & (CPT_MAT_DIFF | CPT_MAT_SPEC | CPT_MAT_TRANS))) return CPT_LOBE_NONE;
+    if (bounce >= P.depth) return CPT_LOBE_NONE;  // the new ray would never be traced
+    LobeProb pr = lobe_probabilities(m);
+    double prob, unused;
+    draw2(P, pixel, sample, (uint32_t)bounce, CPT_STREAM_SELECT, prob, unused);
+    if (prob < pr.diff) return CPT_LOBE_DIFFUSE;
+    if (prob < pr.diff + pr.spec) return CPT_LOBE_MIRROR;
+    return CPT_LOBE_DIELECTRIC;
+}
+
+// reference: src/path_tracer.cu:284-293
+__device__ __forceinline__ void scatter_diffuse(const DScene& sc, const DParams& P, uint32_t pixel, uint32_t sample,
+                                                int bounce, double t, int tri, PathRegs& s) {
+    const cpt_material* m = sc.mats + sc.tris[tri].material;
+    LobeProb pr = lobe_probabilities(m);
+    dvec3 N = shading_normal(sc, tri, s.o, s.d, t);
     dvec3 at = s.o + (t * s.d);
-    if (prob < diffProb) {
-        dvec3 normal = normalize(N);
-        double xa, xb;
-        draw2(P, pixel, sample, (uint32_t)bounce, CPT_STREAM_COSINE, xa, xb);
-        dvec3 rand_dir = cosine_hemisphere(normal, xa, xb);
-        const double pdf = 1 / CPT_PI, theta = 1;
-        s.o = at + normal * 1e-12;
-        s.d = rand_dir;
-        s.medium = 1.0;
-        dvec3 brdf = kd / CPT_PI;
-        s.atten = s.atten * (brdf * theta / (pdf * diffProb));
-    } else if (prob < diffProb + specProb) {
-        dvec3 w_in = normalize(s.d);
-        dvec3 normal = normalize(N);
-        if (s.medium != 1.0) normal = normal * -1.0;
-        dvec3 w_normal = dot(w_in, normal) * normal;
-        dvec3 w_tan = w_in - w_normal;
-        dvec3 w_ref = normalize(-w_normal + w_tan);
-        s.o = at + normal * 1e-12;
-        s.d = w_ref;
-        s.medium = 1.0;  // the reference builds a fresh Ray here, which resets the medium (path_tracer.cu:306)
-        s.atten = s.atten * (ks * 1.0 / specProb);
+    dvec3 normal = normalize(N);
+    double xa, xb;
+    draw2(P, pixel, sample, (uint32_t)bounce, CPT_STREAM_COSINE, xa, xb);
+    dvec3 rand_dir = cosine_hemisphere(normal, xa, xb);
+    const double pdf = 1 / CPT_PI, theta = 1;
+    s.o = at + normal * 1e-12;
+    s.d = rand_dir;
+    s.medium = 1.0;
+    dvec3 brdf = dv(m->kd) / CPT_PI;
+    s.atten = s.atten * (brdf * theta / (pdf * pr.diff));
+}
+
+// reference: src/path_tracer.cu:294-308
+__device__ __forceinline__ void scatter_mirror(const DScene& sc, double t, int tri, PathRegs& s) {
+    const cpt_material* m = sc.mats + sc.tris[tri].material;
+    LobeProb pr = lobe_probabilities(m);
+    dvec3 N = shading_normal(sc, tri, s.o, s.d, t);
+    dvec3 at = s.o + (t * s.d);
+    dvec3 w_in = normalize(s.d);
+    dvec3 normal = normalize(N);
+    if (s.medium != 1.0) normal = normal * -1.0;
+    dvec3 w_normal = dot(w_in, normal) * normal;
+    dvec3 w_tan = w_in - w_normal;
+    dvec3 w_ref = normalize(-w_normal + w_tan);
+    s.o = at + normal * 1e-12;
+    s.d = w_ref;
+    s.medium = 1.0;  // the reference builds a fresh Ray here, which resets the medium (path_tracer.cu:306)
+    s.atten = s.atten * (dv(m->ks) * 1.0 / pr.spec);
+}
+
+// reference: src/path_tracer.cu:310-396
+__device__ __forceinline__ void scatter_dielectric(const DScene& sc, const DParams& P, uint32_t pixel, uint32_t sample,
+                                                   int bounce, double t, int tri, PathRegs& s) {
+    const cpt_material* m = sc.mats + sc.tris[tri].material;
+    LobeProb pr = lobe_probabilities(m);
+    dvec3 N = shading_normal(sc, tri, s.o, s.d, t);
+    dvec3 at = s.o + (t * s.d);
+    dvec3 kt = dv(m->kt);
+    dvec3 w_in = s.d;
+    dvec3 normal = N;
+    double n1, n2;
+    dvec3 tr = dv(1, 1, 1);
+    if (s.medium == 1.0) {
+        n1 = s.medium;
+        n2 = m->index;
     } else {
-        dvec3 w_in = s.d;
-        dvec3 normal = N;
-        double n1, n2;
-        dvec3 tr = dv(1, 1, 1);
-        if (s.medium == 1.0) {
-            n1 = s.medium;
-            n2 = m->index;
-        } else {
-            n1 = m->index;
-            n2 = 1.0;
-            normal = normal * -1.0;
-            tr = dv(pow(kt.x, t), pow(kt.y, t), pow(kt.z, t));
-        }
-        double r0 = (n1 - n2) / (n1 + n2);
-        r0 *= r0;
-        double n = n1 / n2;
-        w_in = -normalize(w_in);
-        double cosI = dot(normal, w_in);
-        double cosR = 1 - n * n * (1 - cosI * cosI);
-        if (cosR >= 0) {
-            double reflCoeff = r0 + (1 - r0) * pow((1 - cosI), 5.0);
-            if (sampleFresnel > reflCoeff) {
-                double cosT = sqrt(cosR);
-                dvec3 refrac = (n * cosI - cosT) * normal - n * w_in;
-                s.o = at - normal * 1e-12;
-                s.d = refrac;
-                s.medium = n2;
-                s.atten = s.atten * tr;
-            } else {
-                dvec3 w2 = s.d;
-                dvec3 nn = N;
-                if (s.medium != 1.0) nn = nn * -1.0;
-                dvec3 w_normal = dot(w2, nn) * nn;
-                dvec3 w_tan = w2 - w_normal;
-                dvec3 w_ref = normalize(-w_normal + w_tan);
-                s.o = at + nn * 1e-12;
-                s.d = w_ref;  // medium kept
-                s.atten = s.atten * ks;
-            }
+        n1 = m->index;
+        n2 = 1.0;
+        normal = normal * -1.0;
+        tr.x = pow(kt.x, t);
+        tr.y = (kt.y == kt.x) ? tr.x : pow(kt.y, t);  // equal inputs give equal results: computed once
+        tr.z = (kt.z == kt.x) ? tr.x : ((kt.z == kt.y) ? tr.y : pow(kt.z, t));
+    }
+    double r0 = (n1 - n2) / (n1 + n2);
+    r0 *= r0;
+    double n = n1 / n2;
+    w_in = -normalize(w_in);
+    double cosI = dot(normal, w_in);
+    double cosR = 1 - n * n * (1 - cosI * cosI);
+    if (cosR >= 0) {
+        double reflCoeff = r0 + (1 - r0) * pow((1 - cosI), 5.0);
+        double unused, sampleFresnel;
+        draw2(P, pixel, sample, (uint32_t)bounce, CPT_STREAM_SELECT, unused, sampleFresnel);
+        if (sampleFresnel > reflCoeff) {
+            double cosT = sqrt(cosR);
+            dvec3 refrac = (n * cosI - cosT) * normal - n * w_in;
+            s.o = at - normal * 1e-12;
+            s.d = refrac;
+            s.medium = n2;
+            s.atten = s.atten * tr;
         } else {
             dvec3 w2 = s.d;
-            dvec3 w_normal = dot(w2, normal) * normal;
+            dvec3 nn = N;
+            if (s.medium != 1.0) nn = nn * -1.0;
+            dvec3 w_normal = dot(w2, nn) * nn;
             dvec3 w_tan = w2 - w_normal;
             dvec3 w_ref = normalize(-w_normal + w_tan);
-            s.o = at + normal * 1e-12;
+            s.o = at + nn * 1e-12;
             s.d = w_ref;  // medium kept
-            s.atten = s.atten * (dv(m->kr) * tr);
+            s.atten = s.atten * dv(m->ks);
         }
-        s.atten = s.atten * (1 / transProb);
+    } else {
+        dvec3 w2 = s.d;
+        dvec3 w_normal = dot(w2, normal) * normal;
+        dvec3 w_tan = w2 - w_normal;
+        dvec3 w_ref = normalize(-w_normal + w_tan);
+        s.o = at + normal * 1e-12;
+        s.d = w_ref;  // medium kept
+        s.atten = s.atten * (dv(m->kr) * tr);
     }
+    s.atten = s.atten * (1 / pr.trans);
+}
+
+__device__ __forceinline__ void scatter(int lobe, const DScene& sc, const DParams& P, uint32_t pixel, uint32_t sample,
+                                        int bounce, double t, int tri, PathRegs& s) {
+    if (lobe == CPT_LOBE_DIFFUSE) scatter_diffuse(sc, P, pixel, sample, bounce, t, tri, s);
+    else if (lobe == CPT_LOBE_MIRROR) scatter_mirror(sc, t, tri, s);
+    else scatter_dielectric(sc, P, pixel, sample, bounce, t, tri, s);
+}
+
+// Both halves in sequence.  Returns true when the path goes on.
+__device__ __forceinline__ bool shade_bounce(const DScene& sc, const DParams& P, uint32_t pixel, uint32_t sample,
+                                             int bounce, double t, int tri, PathRegs& s) {
+    int lobe = choose_lobe(sc, P, pixel, sample, bounce, tri, s.atten, s.color);
+    if (lobe == CPT_LOBE_NONE) return false;
+    scatter(lobe, sc, P, pixel, sample, bounce, t, tri, s);
     return true;
 }
 

@@ -54,11 +54,50 @@ __device__ __forceinline__ void wave_append(uint32_t* queue, uint32_t* counter, 
     if (keep) queue[base + before] = value;
 }
 
+// The same for a whole workgroup: one atomic per workgroup and queue.  A single queue counter takes
+// on the order of 10^8 atomics per second however many CUs issue them, so at one atomic per wave
+// the append, not the shading, sets the pace of a kernel; aggregating over CPT_SHADE_BLOCK threads
+// removes that limit.  Must be reached by every thread of the workgroup.  Handles up to three queues
+// at once (keep[k] selects queue k for this thread; at most one may be set).
+#define CPT_SHADE_BLOCK 512
+#define CPT_SHADE_WAVES (CPT_SHADE_BLOCK / CPT_WAVE)
+template <int NQ>
+__device__ __forceinline__ void block_append(uint32_t* const (&queue)[NQ], uint32_t* const (&counter)[NQ], const bool (&keep)[NQ],
+                                             uint32_t value) {
+    __shared__ uint32_t s_off[NQ][CPT_SHADE_WAVES];
+    __shared__ uint32_t s_base[NQ];
+    const uint32_t lane = threadIdx.x & (CPT_WAVE - 1), wave = threadIdx.x / CPT_WAVE;
+    uint64_t mask[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        mask[k] = __ballot(keep[k]);
+        if (lane == 0) s_off[k][wave] = (uint32_t)__popcll(mask[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        const int k = (int)threadIdx.x;
+        uint32_t total = 0;
+        for (int w = 0; w < CPT_SHADE_WAVES; ++w) {
+            uint32_t c = s_off[k][w];
+            s_off[k][w] = total;
+            total += c;
+        }
+        s_base[k] = total ? atomicAdd(counter[k], total) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)
+        if (keep[k]) queue[k][s_base[k] + s_off[k][wave] + (uint32_t)__popcll(mask[k] & ((1ull << lane) - 1ull))] = value;
+    __syncthreads();
+}
+
 // ---- generate ----------------------------------------------------------------------------
 // One thread per slot of the batch: slot = k * n_pix_slots + pixel slot, sample = batch_s0 + k.
+// Every slot gets a ray and the first bounce's queue is simply 0, 1, 2, ...: slots that have no
+// pixel (image sides that are not multiples of 8) or whose path ends before its first segment get
+// a ray that starts far outside the scene and leaves after one node, and are never resolved.
 // reference: initRays (src/improved_path_tracer.cu:221-251)
-__global__ void __launch_bounds__(CPT_BLOCK) k_generate(DScene sc, DParams P, PathArrays A, int batch_s0, int batch_n,
-                                                        uint32_t* queue, uint32_t* counter) {
+__global__ void __launch_bounds__(CPT_BLOCK) k_generate(DScene sc, DParams P, PathArrays A, int batch_s0, int batch_n) {
     int total = batch_n * P.n_pix_slots;
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += gridDim.x * blockDim.x) {
         int k = slot / P.n_pix_slots, ps = slot - k * P.n_pix_slots;
@@ -66,17 +105,25 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_generate(DScene sc, DParams P, Pa
         bool live = slot_to_pixel(P, ps, i, j);
         PathRegs s;
         s.color = dv(0, 0, 0);
+        s.medium = 1.0;
+        s.atten = dv(1, 1, 1);
         if (live) {
             int sample = batch_s0 + k;
             first_ray(sc, P, i, j, sample, s.o, s.d);
-            s.medium = 1.0;
-            s.atten = dv(1, 1, 1);
             live = roulette(P, (uint32_t)(i + j * P.w), (uint32_t)sample, 0, s);
-            store_ray(A, slot, s);
         }
+        if (!live) {
+            s.o = dv(1e300, 1e300, 1e300);
+            s.d = dv(1, 0, 0);
+            s.atten = dv(0, 0, 0);
+        }
+        store_ray(A, slot, s);
         store_color(A, slot, s);
-        wave_append(queue, counter, live, (uint32_t)slot);
     }
+}
+
+__global__ void k_iota(uint32_t* q, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) q[i] = i;
 }
 
 // ---- extend --------------------------------------------------------------------------------
@@ -141,16 +188,24 @@ static_assert(CPT_PW_STACK_LDS == CPT_PW_STACK_LDS_HOST, "stack split must match
 struct Rec7 {  // the first seven 16-byte pieces of a 128-byte record
     double2 p0, p1, p2, p3, p4, p5, p6;
 };
-__device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, const unsigned char* cache, int cache_first,
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) v2d lds_v2d;
+__device__ __forceinline__ double2 lds_piece(const lds_byte* p) {
+    v2d v = *(const lds_v2d*)p;
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, const lds_byte* cache, int cache_first,
                                              int cached, int idx) {
     Rec7 r;
     if (idx < cached) {
-        const unsigned char* rec = cache + (size_t)(cache_first + idx) * 128;
-        const uint32_t z = ((uint32_t)(cache_first + idx) >> 1) & 7u;
-        r.p0 = *(const double2*)(rec + ((0u ^ z) << 4)); r.p1 = *(const double2*)(rec + ((1u ^ z) << 4));
-        r.p2 = *(const double2*)(rec + ((2u ^ z) << 4)); r.p3 = *(const double2*)(rec + ((3u ^ z) << 4));
-        r.p4 = *(const double2*)(rec + ((4u ^ z) << 4)); r.p5 = *(const double2*)(rec + ((5u ^ z) << 4));
-        r.p6 = *(const double2*)(rec + ((6u ^ z) << 4));
+        const uint32_t slot = (uint32_t)(cache_first + idx);
+        const lds_byte* rec = cache + slot * 128u;
+        const uint32_t z = (slot >> 1) & 7u;
+        r.p0 = lds_piece(rec + ((0u ^ z) << 4)); r.p1 = lds_piece(rec + ((1u ^ z) << 4));
+        r.p2 = lds_piece(rec + ((2u ^ z) << 4)); r.p3 = lds_piece(rec + ((3u ^ z) << 4));
+        r.p4 = lds_piece(rec + ((4u ^ z) << 4)); r.p5 = lds_piece(rec + ((5u ^ z) << 4));
+        r.p6 = lds_piece(rec + ((6u ^ z) << 4));
     } else {
         const double2* g = (const double2*)((const unsigned char*)base + (size_t)idx * 128);
         r.p0 = g[0]; r.p1 = g[1]; r.p2 = g[2]; r.p3 = g[3]; r.p4 = g[4]; r.p5 = g[5]; r.p6 = g[6];
@@ -180,6 +235,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, PathArr
         *(double2*)(s_cache + (size_t)r * 128 + (((uint32_t)c ^ (((uint32_t)r >> 1) & 7u)) << 4)) = *(const double2*)(src + c * 16);
     }
     __syncthreads();
+    const lds_byte* cache = (const lds_byte*)s_cache;
 
     uint32_t* my_nodes = &s_nodes[wave][0][lane];    // entry e at my_nodes[e * CPT_WAVE]
     uint32_t* my_leaves = &s_leaves[wave][0][lane];
@@ -242,7 +298,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, PathArr
 
         // ---- box phase: expand one node per lane that has one (and room to park two more leaves) ----
         if (node >= 0 && lp <= CPT_PW_LEAF_CAP - 2) {
-            Rec7 r = fetch_record(sc.nodes, s_cache, 0, cached_nodes, node);
+            Rec7 r = fetch_record(sc.nodes, cache, 0, cached_nodes, node);
             int2 refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));  // lref, rref
             bool sure_l, sure_r;
             bool hl = slab_filtered(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, rinv, sure_l);
@@ -282,7 +338,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, PathArr
                 if (lp > 0) {
                     --lp;
                     int tri = (int)my_leaves[lp * CPT_WAVE];
-                    Rec7 q = fetch_record(sc.tris, s_cache, cached_nodes, cached_tris, tri);
+                    Rec7 q = fetch_record(sc.tris, cache, cached_nodes, cached_tris, tri);
                     uint32_t flags = (uint32_t)__double2hiint(q.p6.x), rank = (uint32_t)__double2loint(q.p6.y);
                     double t;
                     if (COUNT) tris++;
@@ -309,12 +365,12 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, PathArr
 // ---- shade + compact -------------------------------------------------------------------------
 // reference: the shading half of pathTrace (src/improved_path_tracer.cu:77-215)
 template <bool COUNT>
-__global__ void __launch_bounds__(CPT_BLOCK) k_shade(DScene sc, DParams P, PathArrays A, int batch_s0, int bounce,
+__global__ void __launch_bounds__(CPT_SHADE_BLOCK) k_shade(DScene sc, DParams P, PathArrays A, int batch_s0, int bounce,
                                                      const uint32_t* __restrict__ queue_in,
                                                      const uint32_t* __restrict__ counter_in, uint32_t* queue_out,
                                                      uint32_t* counter_out, unsigned long long* work) {
     uint32_t n = *counter_in;
-    uint32_t n_round = (n + CPT_WAVE - 1) / CPT_WAVE * CPT_WAVE;  // whole waves reach wave_append together
+    uint32_t n_round = (n + CPT_SHADE_BLOCK - 1) / CPT_SHADE_BLOCK * CPT_SHADE_BLOCK;  // whole workgroups reach block_append together
     unsigned long long hits = 0, segs = 0;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_round; q += gridDim.x * blockDim.x) {
         bool go = false;
@@ -335,11 +391,96 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_shade(DScene sc, DParams P, PathA
             if (go) store_ray(A, slot, s);
             store_color(A, slot, s);
         }
-        wave_append(queue_out, counter_out, go, (uint32_t)slot);
+        uint32_t* const qs[1] = {queue_out};
+        uint32_t* const cs[1] = {counter_out};
+        const bool ks[1] = {go};
+        block_append<1>(qs, cs, ks, (uint32_t)slot);
     }
     if (COUNT) {
         if (segs) atomicAdd(&work[1], segs);
         if (hits) atomicAdd(&work[2], hits);
+    }
+}
+
+// ---- shade, split by lobe ---------------------------------------------------------------------------
+// The single shade kernel runs three very different scatter routines under one roof, and a wave
+// whose lanes chose different lobes pays for all of them.  Split form: k_select does what every hit
+// needs (emission, termination, lobe choice) and sorts the surviving slots into one queue per lobe;
+// k_scatter<LOBE> then runs one routine over its own queue with every lane doing the same thing, and
+// appends to the next bounce's queue (which so arrives grouped by lobe).
+__global__ void __launch_bounds__(CPT_SHADE_BLOCK) k_select(DScene sc, DParams P, PathArrays A, int batch_s0, int bounce,
+                                                      const uint32_t* __restrict__ queue_in,
+                                                      const uint32_t* __restrict__ counter_in, uint32_t* lobe_queues,
+                                                      size_t lobe_stride, uint32_t* lobe_counters,
+                                                      unsigned long long* work) {
+    uint32_t n = *counter_in;
+    uint32_t n_round = (n + CPT_SHADE_BLOCK - 1) / CPT_SHADE_BLOCK * CPT_SHADE_BLOCK;
+    unsigned long long hits = 0, segs = 0;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_round; q += gridDim.x * blockDim.x) {
+        int lobe = CPT_LOBE_NONE;
+        int slot = 0;
+        if (q < n) {
+            slot = (int)queue_in[q];
+            int tri = A.hit_tri[slot];
+            if (work) { segs++; hits += (tri >= 0); }
+            if (tri >= 0) {
+                int k = slot / P.n_pix_slots, ps = slot - k * P.n_pix_slots;
+                int i, j;
+                slot_to_pixel(P, ps, i, j);
+                dvec3 atten = dv(A.ax[slot], A.ay[slot], A.az[slot]);
+                dvec3 color = dv(A.cx[slot], A.cy[slot], A.cz[slot]);
+                dvec3 before = color;
+                lobe = choose_lobe(sc, P, (uint32_t)(i + j * P.w), (uint32_t)(batch_s0 + k), bounce, tri, atten, color);
+                if (color.x != before.x || color.y != before.y || color.z != before.z) {
+                    A.cx[slot] = color.x; A.cy[slot] = color.y; A.cz[slot] = color.z;
+                }
+            }
+        }
+        uint32_t* const qs[3] = {lobe_queues, lobe_queues + lobe_stride, lobe_queues + 2 * lobe_stride};
+        uint32_t* const cs[3] = {lobe_counters, lobe_counters + 1, lobe_counters + 2};
+        const bool ks[3] = {lobe == CPT_LOBE_DIFFUSE, lobe == CPT_LOBE_MIRROR, lobe == CPT_LOBE_DIELECTRIC};
+        block_append<3>(qs, cs, ks, (uint32_t)slot);
+    }
+    if (work) {
+        if (segs) atomicAdd(&work[1], segs);
+        if (hits) atomicAdd(&work[2], hits);
+    }
+}
+
+template <int LOBE>
+__global__ void __launch_bounds__(CPT_SHADE_BLOCK) k_scatter(DScene sc, DParams P, PathArrays A, int batch_s0, int bounce,
+                                                       const uint32_t* __restrict__ queue_in,
+                                                       const uint32_t* __restrict__ counter_in, uint32_t* queue_out,
+                                                       uint32_t* counter_out) {
+    uint32_t n = *counter_in;
+    uint32_t n_round = (n + CPT_SHADE_BLOCK - 1) / CPT_SHADE_BLOCK * CPT_SHADE_BLOCK;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_round; q += gridDim.x * blockDim.x) {
+        bool go = false;
+        int slot = 0;
+        if (q < n) {
+            slot = (int)queue_in[q];
+            int k = slot / P.n_pix_slots, ps = slot - k * P.n_pix_slots;
+            int i, j;
+            slot_to_pixel(P, ps, i, j);
+            uint32_t pixel = (uint32_t)(i + j * P.w), sample = (uint32_t)(batch_s0 + k);
+            PathRegs s;
+            s.o = dv(A.ox[slot], A.oy[slot], A.oz[slot]);
+            s.d = dv(A.dx[slot], A.dy[slot], A.dz[slot]);
+            s.medium = A.medium[slot];
+            s.atten = dv(A.ax[slot], A.ay[slot], A.az[slot]);
+            s.color = dv(0, 0, 0);
+            double t = A.hit_t[slot];
+            int tri = A.hit_tri[slot];
+            if (LOBE == CPT_LOBE_DIFFUSE) scatter_diffuse(sc, P, pixel, sample, bounce, t, tri, s);
+            else if (LOBE == CPT_LOBE_MIRROR) scatter_mirror(sc, t, tri, s);
+            else scatter_dielectric(sc, P, pixel, sample, bounce, t, tri, s);
+            go = roulette(P, pixel, sample, bounce + 1, s);
+            if (go) store_ray(A, slot, s);
+        }
+        uint32_t* const qs[1] = {queue_out};
+        uint32_t* const cs[1] = {counter_out};
+        const bool ks[1] = {go};
+        block_append<1>(qs, cs, ks, (uint32_t)slot);
     }
 }
 
@@ -504,10 +645,19 @@ static inline int grid_for(long long n_threads, int max_blocks) {
     return (int)b;
 }
 
-void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int batch_n,
-                     uint32_t* queue, uint32_t* counter) {
+void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int batch_n) {
     int g = grid_for((long long)batch_n * P.n_pix_slots, L.max_blocks);
-    hipLaunchKernelGGL(k_generate, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, A, batch_s0, batch_n, queue, counter);
+    hipLaunchKernelGGL(k_generate, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, A, batch_s0, batch_n);
+}
+void launch_iota(const LaunchCfg& L, uint32_t* q, long long n) {
+    int g = grid_for(n, L.max_blocks);
+    hipLaunchKernelGGL(k_iota, dim3(g), dim3(CPT_BLOCK), 0, L.stream, q, (uint32_t)n);
+}
+static inline int shade_grid(long long n_threads, int max_blocks) {
+    long long b = (n_threads + CPT_SHADE_BLOCK - 1) / CPT_SHADE_BLOCK;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
 }
 void launch_extend(const LaunchCfg& L, const DScene& sc, const PathArrays& A, const uint32_t* queue, const uint32_t* counter,
                    long long max_entries, unsigned long long* work) {
@@ -525,9 +675,23 @@ void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const PathArrays& A,
 void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int bounce,
                   const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* queue_out, uint32_t* counter_out,
                   long long max_entries, unsigned long long* work) {
-    int g = grid_for(max_entries, L.max_blocks);
-    if (work) hipLaunchKernelGGL(k_shade<true>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, queue_out, counter_out, work);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, queue_out, counter_out, work);
+    int g = shade_grid(max_entries, L.max_blocks);
+    if (work) hipLaunchKernelGGL(k_shade<true>, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, queue_out, counter_out, work);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, queue_out, counter_out, work);
+}
+void launch_select(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int bounce,
+                   const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* lobe_queues, size_t lobe_stride,
+                   uint32_t* lobe_counters, long long max_entries, unsigned long long* work) {
+    int g = shade_grid(max_entries, L.max_blocks);
+    hipLaunchKernelGGL(k_select, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, lobe_queues, lobe_stride, lobe_counters, work);
+}
+void launch_scatter(const LaunchCfg& L, int lobe, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0,
+                    int bounce, const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* queue_out,
+                    uint32_t* counter_out, long long max_entries) {
+    int g = shade_grid(max_entries, L.max_blocks);
+    if (lobe == CPT_LOBE_DIFFUSE) hipLaunchKernelGGL(k_scatter<CPT_LOBE_DIFFUSE>, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, queue_out, counter_out);
+    else if (lobe == CPT_LOBE_MIRROR) hipLaunchKernelGGL(k_scatter<CPT_LOBE_MIRROR>, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, queue_out, counter_out);
+    else hipLaunchKernelGGL(k_scatter<CPT_LOBE_DIELECTRIC>, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, queue_out, counter_out);
 }
 void launch_resolve(const LaunchCfg& L, const DParams& P, const PathArrays& A, int batch_n, double* accum) {
     int g = grid_for(P.n_pix_slots, L.max_blocks);

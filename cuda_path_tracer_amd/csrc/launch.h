@@ -49,8 +49,8 @@ struct LaunchCfg {
     int pw_chunk;    // queue entries a wave takes per atomic
 };
 
-void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int batch_n,
-                     uint32_t* queue, uint32_t* counter);
+void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int batch_n);
+void launch_iota(const LaunchCfg& L, uint32_t* q, long long n);
 void launch_extend(const LaunchCfg& L, const DScene& sc, const PathArrays& A, const uint32_t* queue, const uint32_t* counter,
                    long long max_entries, unsigned long long* work);
 void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const PathArrays& A, const uint32_t* queue, const uint32_t* counter,
@@ -58,6 +58,12 @@ void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const PathArrays& A,
 void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int bounce,
                   const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* queue_out, uint32_t* counter_out,
                   long long max_entries, unsigned long long* work);
+void launch_select(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int bounce,
+                   const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* lobe_queues, size_t lobe_stride,
+                   uint32_t* lobe_counters, long long max_entries, unsigned long long* work);
+void launch_scatter(const LaunchCfg& L, int lobe, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0,
+                    int bounce, const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* queue_out,
+                    uint32_t* counter_out, long long max_entries);
 void launch_resolve(const LaunchCfg& L, const DParams& P, const PathArrays& A, int batch_n, double* accum);
 void launch_megakernel(const LaunchCfg& L, const DScene& sc, const DParams& P, double* accum, unsigned long long* work);
 void launch_tonemap(const LaunchCfg& L, const double* accum, int n_values, int spp, uint8_t* rgb);
