@@ -31,13 +31,12 @@ struct cpt_ctx {
     bool has_scene = false;
     int n_tree_nodes = 0, tree_height = 0;
 
-    void* d_paths = nullptr;
-    size_t path_capacity = 0;
-    PathArrays A{};
-    uint32_t* d_queue[2] = {nullptr, nullptr};
-    uint32_t* d_lobe_queues = nullptr;     // three queues of path_capacity entries each
-    uint32_t* d_identity = nullptr;        // 0, 1, 2, ...: the queue of every batch's first bounce
-    uint32_t* d_counters = nullptr;        // CPT_MAX_DEPTH + 2 queue lengths, as many queue cursors, 3x as many lobe queue lengths
+    void* d_paths = nullptr;               // one allocation: two ray streams, hit buffer, per-slot radiance
+    size_t path_capacity = 0;              // in path slots
+    RayStream R[2]{};
+    HitBuf H{};
+    Radiance C{};
+    uint32_t* d_counters = nullptr;        // CPT_MAX_DEPTH + 2 stream lengths, then as many claim cursors
     unsigned long long* d_work = nullptr;  // paths, segments, hits, node steps, triangle tests
     uint32_t* d_spill = nullptr;           // stack overflow columns of the persistent-wave extend kernel
     int spill_blocks = 0;
@@ -51,7 +50,6 @@ struct cpt_ctx {
     int pw_blocks = 0;             // persistent workgroups of the extend kernel (one per CU)
     int pw_chunk = 256;            // queue entries a persistent wave takes per atomic
     int extend_variant = 1;        // 0: one ray per thread; 1: persistent waves with refill
-    int shade_variant = 0;         // 0: one shade kernel; 1: select + one scatter kernel per lobe (slower: more scattered state traffic)
 };
 
 static thread_local std::string g_create_error;
@@ -82,14 +80,7 @@ static void free_scene(cpt_ctx* c) {
 }
 static void free_paths(cpt_ctx* c) {
     if (c->d_paths) (void)hipFree(c->d_paths);
-    if (c->d_queue[0]) (void)hipFree(c->d_queue[0]);
-    if (c->d_queue[1]) (void)hipFree(c->d_queue[1]);
-    if (c->d_lobe_queues) (void)hipFree(c->d_lobe_queues);
-    if (c->d_identity) (void)hipFree(c->d_identity);
-    c->d_lobe_queues = nullptr;
-    c->d_identity = nullptr;
     c->d_paths = nullptr;
-    c->d_queue[0] = c->d_queue[1] = nullptr;
     c->path_capacity = 0;
 }
 
@@ -112,7 +103,7 @@ int cpt_create(int device, cpt_ctx** out) {
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(nullptr, CPT_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
-    e = hipMalloc((void**)&c->d_counters, 5 * (CPT_MAX_DEPTH + 2) * sizeof(uint32_t));
+    e = hipMalloc((void**)&c->d_counters, 2 * (CPT_MAX_DEPTH + 2) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_work, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->d_work, 0, 8 * sizeof(unsigned long long));
     if (e != hipSuccess) { cpt_destroy(c); return fail(nullptr, CPT_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
@@ -163,9 +154,6 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
     } else if (!strcmp(key, "pw_chunk")) {
         if (value < 1 || value > (1 << 20)) return fail(c, CPT_EINVAL, "pw_chunk must be in [1, 2^20]");
         c->pw_chunk = (int)value;
-    } else if (!strcmp(key, "shade_variant")) {
-        if (value != 0 && value != 1) return fail(c, CPT_EINVAL, "shade_variant must be 0 or 1");
-        c->shade_variant = (int)value;
     } else if (!strcmp(key, "extend_variant")) {
         if (value != 0 && value != 1) return fail(c, CPT_EINVAL, "extend_variant must be 0 or 1");
         c->extend_variant = (int)value;
@@ -260,21 +248,22 @@ static int ensure_paths(cpt_ctx* c, size_t slots) {
     if (slots <= c->path_capacity) return CPT_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_paths(c);
-    HIP_TRY(c, hipMalloc(&c->d_paths, slots * CPT_PATH_BYTES));
-    HIP_TRY(c, hipMalloc((void**)&c->d_queue[0], slots * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_queue[1], slots * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_lobe_queues, 3 * slots * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_identity, slots * sizeof(uint32_t)));
-    {
-        LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk};
-        launch_iota(L, c->d_identity, (long long)slots);
-        HIP_TRY(c, hipGetLastError());
+    slots = (slots + 63) / 64 * 64;  // keeps every array 512-byte aligned
+    HIP_TRY(c, hipMalloc(&c->d_paths, slots * CPT_SLOT_BYTES));
+    double* p = (double*)c->d_paths;
+    for (int b = 0; b < 2; ++b) {
+        double** f[CPT_STREAM_DOUBLES] = {&c->R[b].ox, &c->R[b].oy, &c->R[b].oz, &c->R[b].dx, &c->R[b].dy, &c->R[b].dz,
+                                          &c->R[b].medium, &c->R[b].ax, &c->R[b].ay, &c->R[b].az};
+        for (int k = 0; k < CPT_STREAM_DOUBLES; ++k) { *f[k] = p; p += slots; }
     }
-    double* base = (double*)c->d_paths;
-    double** fields[CPT_PATH_DOUBLES] = {&c->A.ox, &c->A.oy, &c->A.oz, &c->A.dx, &c->A.dy, &c->A.dz, &c->A.medium,
-                                         &c->A.ax, &c->A.ay, &c->A.az, &c->A.cx, &c->A.cy, &c->A.cz, &c->A.hit_t};
-    for (int f = 0; f < CPT_PATH_DOUBLES; ++f) *fields[f] = base + (size_t)f * slots;
-    c->A.hit_tri = (int*)(base + (size_t)CPT_PATH_DOUBLES * slots);
+    c->H.t = p; p += slots;
+    c->C.cx = p; p += slots;
+    c->C.cy = p; p += slots;
+    c->C.cz = p; p += slots;
+    uint32_t* u = (uint32_t*)p;
+    c->R[0].slot = u; u += slots;
+    c->R[1].slot = u; u += slots;
+    c->H.tri = (int*)u;
     c->path_capacity = slots;
     return CPT_OK;
 }
@@ -367,30 +356,19 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
         uint32_t* cursors = c->d_counters + (CPT_MAX_DEPTH + 2);
         HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, (size_t)(P.depth + 2) * sizeof(uint32_t), c->stream));
         HIP_TRY(c, hipMemsetAsync(cursors, 0, (size_t)(P.depth + 2) * sizeof(uint32_t), c->stream));
-        uint32_t* lobe_counters = c->d_counters + 2 * (CPT_MAX_DEPTH + 2);
-        if (c->shade_variant == 1) HIP_TRY(c, hipMemsetAsync(lobe_counters, 0, 3 * (size_t)(P.depth + 2) * sizeof(uint32_t), c->stream));
         if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
         HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_counters, (int)slots, 1, c->stream));
-        launch_generate(L, c->sc, P, c->A, bs, bn);
+        launch_generate(L, c->sc, P, c->R[0], c->C, bs, bn);
         if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
         for (int b = 0; b <= P.depth; ++b) {
-            const uint32_t* q_in = b == 0 ? c->d_identity : c->d_queue[b & 1];
-            if (c->extend_variant == 1) launch_extend_pw(L, c->sc, c->A, q_in, c->d_counters + b, cursors + b, c->d_spill, slots, work);
-            else launch_extend(L, c->sc, c->A, q_in, c->d_counters + b, slots, work);
+            const RayStream& in = c->R[b & 1];
+            if (c->extend_variant == 1) launch_extend_pw(L, c->sc, in, c->H, c->d_counters + b, cursors + b, c->d_spill, work);
+            else launch_extend(L, c->sc, in, c->H, c->d_counters + b, slots, work);
             if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
-            if (c->shade_variant == 1) {
-                uint32_t* lc = lobe_counters + 3 * b;
-                launch_select(L, c->sc, P, c->A, bs, b, q_in, c->d_counters + b, c->d_lobe_queues, c->path_capacity, lc, slots, work);
-                for (int lobe = 0; lobe < 3; ++lobe)
-                    launch_scatter(L, lobe, c->sc, P, c->A, bs, b, c->d_lobe_queues + (size_t)lobe * c->path_capacity, lc + lobe,
-                                   c->d_queue[(b + 1) & 1], c->d_counters + b + 1, slots);
-            } else {
-                launch_shade(L, c->sc, P, c->A, bs, b, q_in, c->d_counters + b, c->d_queue[(b + 1) & 1],
-                             c->d_counters + b + 1, slots, work);
-            }
+            launch_shade(L, c->sc, P, in, c->H, c->R[(b + 1) & 1], c->C, bs, b, c->d_counters + b, c->d_counters + b + 1, slots, work);
             if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
         }
-        launch_resolve(L, P, c->A, bn, d_accum);
+        launch_resolve(L, P, c->C, bn, d_accum);
         HIP_TRY(c, hipGetLastError());
         c->stats.launches_generate++;
         c->stats.launches_extend += (uint64_t)(P.depth + 1);

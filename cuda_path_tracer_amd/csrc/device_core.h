@@ -348,13 +348,15 @@ __device__ __forceinline__ LobeProb lobe_probabilities(const cpt_material* m) {
     return p;
 }
 
-// Emission and lobe choice for a hit on triangle `tri` (tri < 0: the ray missed).  Updates `color`
-// with the throughput `atten`; returns the lobe to scatter with, or CPT_LOBE_NONE when the path ends.
+// Emission and lobe choice for a hit on triangle `tri` (tri < 0: the ray missed).  `emitted` receives
+// ke * throughput, which the caller adds to the path's radiance; returns the lobe to scatter with, or
+// CPT_LOBE_NONE when the path ends.
 __device__ __forceinline__ int choose_lobe(const DScene& sc, const DParams& P, uint32_t pixel, uint32_t sample, int bounce,
-                                           int tri, const dvec3& atten, dvec3& color) {
+                                           int tri, const dvec3& atten, dvec3& emitted) {
+    emitted = dv(0, 0, 0);
     if (tri < 0) return CPT_LOBE_NONE;  // the reference re-intersects the same missing ray until the loop ends
     const cpt_material* m = sc.mats + sc.tris[tri].material;
-    color = color + dv(m->ke) * atten;
+    emitted = dv(m->ke) * atten;
     if (!(m->flags & (CPT_MAT_DIFF | CPT_MAT_SPEC | CPT_MAT_TRANS))) return CPT_LOBE_NONE;
     if (bounce >= P.depth) return CPT_LOBE_NONE;  // the new ray would never be traced
     LobeProb pr = lobe_probabilities(m);
@@ -365,117 +367,113 @@ __device__ __forceinline__ int choose_lobe(const DScene& sc, const DParams& P, u
     return CPT_LOBE_DIELECTRIC;
 }
 
-// reference: src/path_tracer.cu:284-293
-__device__ __forceinline__ void scatter_diffuse(const DScene& sc, const DParams& P, uint32_t pixel, uint32_t sample,
-                                                int bounce, double t, int tri, PathRegs& s) {
-    const cpt_material* m = sc.mats + sc.tris[tri].material;
-    LobeProb pr = lobe_probabilities(m);
-    dvec3 N = shading_normal(sc, tri, s.o, s.d, t);
-    dvec3 at = s.o + (t * s.d);
-    dvec3 normal = normalize(N);
-    double xa, xb;
-    draw2(P, pixel, sample, (uint32_t)bounce, CPT_STREAM_COSINE, xa, xb);
-    dvec3 rand_dir = cosine_hemisphere(normal, xa, xb);
-    const double pdf = 1 / CPT_PI, theta = 1;
-    s.o = at + normal * 1e-12;
-    s.d = rand_dir;
-    s.medium = 1.0;
-    dvec3 brdf = dv(m->kd) / CPT_PI;
-    s.atten = s.atten * (brdf * theta / (pdf * pr.diff));
-}
-
-// reference: src/path_tracer.cu:294-308
-__device__ __forceinline__ void scatter_mirror(const DScene& sc, double t, int tri, PathRegs& s) {
-    const cpt_material* m = sc.mats + sc.tris[tri].material;
-    LobeProb pr = lobe_probabilities(m);
-    dvec3 N = shading_normal(sc, tri, s.o, s.d, t);
-    dvec3 at = s.o + (t * s.d);
-    dvec3 w_in = normalize(s.d);
-    dvec3 normal = normalize(N);
-    if (s.medium != 1.0) normal = normal * -1.0;
-    dvec3 w_normal = dot(w_in, normal) * normal;
-    dvec3 w_tan = w_in - w_normal;
-    dvec3 w_ref = normalize(-w_normal + w_tan);
-    s.o = at + normal * 1e-12;
-    s.d = w_ref;
-    s.medium = 1.0;  // the reference builds a fresh Ray here, which resets the medium (path_tracer.cu:306)
-    s.atten = s.atten * (dv(m->ks) * 1.0 / pr.spec);
-}
-
-// reference: src/path_tracer.cu:310-396
-__device__ __forceinline__ void scatter_dielectric(const DScene& sc, const DParams& P, uint32_t pixel, uint32_t sample,
-                                                   int bounce, double t, int tri, PathRegs& s) {
-    const cpt_material* m = sc.mats + sc.tris[tri].material;
-    LobeProb pr = lobe_probabilities(m);
-    dvec3 N = shading_normal(sc, tri, s.o, s.d, t);
-    dvec3 at = s.o + (t * s.d);
-    dvec3 kt = dv(m->kt);
-    dvec3 w_in = s.d;
-    dvec3 normal = N;
-    double n1, n2;
-    dvec3 tr = dv(1, 1, 1);
-    if (s.medium == 1.0) {
-        n1 = s.medium;
-        n2 = m->index;
-    } else {
-        n1 = m->index;
-        n2 = 1.0;
-        normal = normal * -1.0;
-        tr.x = pow(kt.x, t);
-        tr.y = (kt.y == kt.x) ? tr.x : pow(kt.y, t);  // equal inputs give equal results: computed once
-        tr.z = (kt.z == kt.x) ? tr.x : ((kt.z == kt.y) ? tr.y : pow(kt.z, t));
-    }
-    double r0 = (n1 - n2) / (n1 + n2);
-    r0 *= r0;
-    double n = n1 / n2;
-    w_in = -normalize(w_in);
-    double cosI = dot(normal, w_in);
-    double cosR = 1 - n * n * (1 - cosI * cosI);
-    if (cosR >= 0) {
-        double reflCoeff = r0 + (1 - r0) * pow((1 - cosI), 5.0);
-        double unused, sampleFresnel;
-        draw2(P, pixel, sample, (uint32_t)bounce, CPT_STREAM_SELECT, unused, sampleFresnel);
-        if (sampleFresnel > reflCoeff) {
-            double cosT = sqrt(cosR);
-            dvec3 refrac = (n * cosI - cosT) * normal - n * w_in;
-            s.o = at - normal * 1e-12;
-            s.d = refrac;
-            s.medium = n2;
-            s.atten = s.atten * tr;
-        } else {
-            dvec3 w2 = s.d;
-            dvec3 nn = N;
-            if (s.medium != 1.0) nn = nn * -1.0;
-            dvec3 w_normal = dot(w2, nn) * nn;
-            dvec3 w_tan = w2 - w_normal;
-            dvec3 w_ref = normalize(-w_normal + w_tan);
-            s.o = at + nn * 1e-12;
-            s.d = w_ref;  // medium kept
-            s.atten = s.atten * dv(m->ks);
-        }
-    } else {
-        dvec3 w2 = s.d;
-        dvec3 w_normal = dot(w2, normal) * normal;
-        dvec3 w_tan = w2 - w_normal;
-        dvec3 w_ref = normalize(-w_normal + w_tan);
-        s.o = at + normal * 1e-12;
-        s.d = w_ref;  // medium kept
-        s.atten = s.atten * (dv(m->kr) * tr);
-    }
-    s.atten = s.atten * (1 / pr.trans);
-}
-
+// Scatter with the chosen lobe: replace the ray, scale the throughput.
+// reference: src/path_tracer.cu:284-396.
+//
+// The three lobes are written as one routine so that a wave whose lanes chose different lobes runs
+// the expensive common pieces once: the shading normal, and the mirror-reflection block that the
+// mirror lobe, the dielectric lobe's Fresnel reflection and total internal reflection all end in
+// (each with its own incoming direction, normal and throughput factor, exactly as the reference
+// writes them).
 __device__ __forceinline__ void scatter(int lobe, const DScene& sc, const DParams& P, uint32_t pixel, uint32_t sample,
                                         int bounce, double t, int tri, PathRegs& s) {
-    if (lobe == CPT_LOBE_DIFFUSE) scatter_diffuse(sc, P, pixel, sample, bounce, t, tri, s);
-    else if (lobe == CPT_LOBE_MIRROR) scatter_mirror(sc, t, tri, s);
-    else scatter_dielectric(sc, P, pixel, sample, bounce, t, tri, s);
+    const cpt_material* m = sc.mats + sc.tris[tri].material;
+    const LobeProb pr = lobe_probabilities(m);
+    const dvec3 N = shading_normal(sc, tri, s.o, s.d, t);
+    const dvec3 at = s.o + (t * s.d);
+
+    bool reflects = false;        // ends in the reflection block below
+    dvec3 rw = s.d, rn = N;       // incoming direction and normal the reflection uses
+    dvec3 f1 = dv(1, 1, 1);       // throughput factor of the reflection
+    bool lobe_weight = false;     // dielectric outcomes are also divided by the lobe's probability
+    bool reset_medium = false;
+
+    if (lobe == CPT_LOBE_DIFFUSE) {  // :284-293
+        dvec3 normal = normalize(N);
+        double xa, xb;
+        draw2(P, pixel, sample, (uint32_t)bounce, CPT_STREAM_COSINE, xa, xb);
+        dvec3 rand_dir = cosine_hemisphere(normal, xa, xb);
+        const double pdf = 1 / CPT_PI, theta = 1;
+        s.o = at + normal * 1e-12;
+        s.d = rand_dir;
+        s.medium = 1.0;
+        dvec3 brdf = dv(m->kd) / CPT_PI;
+        s.atten = s.atten * (brdf * theta / (pdf * pr.diff));
+    } else if (lobe == CPT_LOBE_MIRROR) {  // :294-308
+        rw = normalize(s.d);
+        rn = normalize(N);
+        if (s.medium != 1.0) rn = rn * -1.0;
+        f1 = dv(m->ks) * 1.0 / pr.spec;
+        reset_medium = true;  // the reference builds a fresh Ray here, which resets the medium (:306)
+        reflects = true;
+    } else {  // :310-396
+        dvec3 kt = dv(m->kt);
+        dvec3 w_in = s.d;
+        dvec3 normal = N;
+        double n1, n2;
+        dvec3 tr = dv(1, 1, 1);
+        if (s.medium == 1.0) {
+            n1 = s.medium;
+            n2 = m->index;
+        } else {
+            n1 = m->index;
+            n2 = 1.0;
+            normal = normal * -1.0;
+            tr.x = pow(kt.x, t);
+            tr.y = (kt.y == kt.x) ? tr.x : pow(kt.y, t);  // equal inputs give equal results: computed once
+            tr.z = (kt.z == kt.x) ? tr.x : ((kt.z == kt.y) ? tr.y : pow(kt.z, t));
+        }
+        double r0 = (n1 - n2) / (n1 + n2);
+        r0 *= r0;
+        double n = n1 / n2;
+        w_in = -normalize(w_in);
+        double cosI = dot(normal, w_in);
+        double cosR = 1 - n * n * (1 - cosI * cosI);
+        lobe_weight = true;
+        if (cosR >= 0) {
+            double reflCoeff = r0 + (1 - r0) * pow((1 - cosI), 5.0);
+            double unused, sampleFresnel;
+            draw2(P, pixel, sample, (uint32_t)bounce, CPT_STREAM_SELECT, unused, sampleFresnel);
+            if (sampleFresnel > reflCoeff) {  // refraction
+                double cosT = sqrt(cosR);
+                dvec3 refrac = (n * cosI - cosT) * normal - n * w_in;
+                s.o = at - normal * 1e-12;
+                s.d = refrac;
+                s.medium = n2;
+                s.atten = s.atten * tr;
+                s.atten = s.atten * (1 / pr.trans);
+            } else {  // Fresnel reflection about the geometric-side normal, medium kept
+                rw = s.d;
+                rn = N;
+                if (s.medium != 1.0) rn = rn * -1.0;
+                f1 = dv(m->ks);
+                reflects = true;
+            }
+        } else {  // total internal reflection, medium kept
+            rw = s.d;
+            rn = normal;
+            f1 = dv(m->kr) * tr;
+            reflects = true;
+        }
+    }
+    if (reflects) {
+        dvec3 w_normal = dot(rw, rn) * rn;
+        dvec3 w_tan = rw - w_normal;
+        dvec3 w_ref = normalize(-w_normal + w_tan);
+        s.o = at + rn * 1e-12;
+        s.d = w_ref;
+        if (reset_medium) s.medium = 1.0;
+        s.atten = s.atten * f1;
+        if (lobe_weight) s.atten = s.atten * (1 / pr.trans);
+    }
 }
 
 // Both halves in sequence.  Returns true when the path goes on.
 __device__ __forceinline__ bool shade_bounce(const DScene& sc, const DParams& P, uint32_t pixel, uint32_t sample,
                                              int bounce, double t, int tri, PathRegs& s) {
-    int lobe = choose_lobe(sc, P, pixel, sample, bounce, tri, s.atten, s.color);
+    dvec3 emitted;
+    int lobe = choose_lobe(sc, P, pixel, sample, bounce, tri, s.atten, emitted);
+    s.color = s.color + emitted;
     if (lobe == CPT_LOBE_NONE) return false;
     scatter(lobe, sc, P, pixel, sample, bounce, t, tri, s);
     return true;

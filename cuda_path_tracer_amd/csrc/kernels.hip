@@ -2,13 +2,14 @@
 //
 // Wavefront pipeline (the product): a batch holds S samples of every pixel as S * n_pix_slots path
 // slots.  generate writes every slot's first ray; then, once per bounce, extend intersects the rays
-// of the live queue and shade consumes the hits, writes the next rays and compacts the survivors
-// into the next queue (one ballot + popcount prefix + one atomic per wave).  resolve folds the
-// batch's per-path radiance into the per-pixel accumulation buffer in sample order, so the sum a
-// pixel receives is the same sequence of fp64 additions whatever the batch size.
+// of the current stream and shade consumes the hits and writes the surviving paths, compacted, to
+// the other stream (workgroup-wide ballot + popcount prefix, one atomic per workgroup).  resolve
+// folds the batch's per-path radiance into the per-pixel accumulation buffer in sample order, so
+// the sum a pixel receives is the same sequence of fp64 additions whatever the batch size.
 //
-// Path state is structure-of-arrays in HBM, indexed by slot; slots enumerate 8x8 pixel tiles so a
-// wave's 64 first rays are neighbours and its state accesses are contiguous.
+// Ray state is structure-of-arrays in HBM and is indexed by position in the stream, not by path:
+// extend and shade read and write contiguous runs.  Slots enumerate 8x8 pixel tiles, so a wave's 64
+// first rays are neighbours.
 #include <hip/hip_runtime.h>
 
 #include "device_core.h"
@@ -22,89 +23,64 @@
     __shared__ uint32_t s_stack[CPT_WAVES_PER_BLOCK][CPT_STACK_ENTRIES][CPT_WAVE];          \
     uint32_t* my_stack = &s_stack[threadIdx.x / CPT_WAVE][0][threadIdx.x % CPT_WAVE];
 
-__device__ __forceinline__ void load_path(const PathArrays& A, int slot, PathRegs& s) {
-    s.o = dv(A.ox[slot], A.oy[slot], A.oz[slot]);
-    s.d = dv(A.dx[slot], A.dy[slot], A.dz[slot]);
-    s.medium = A.medium[slot];
-    s.atten = dv(A.ax[slot], A.ay[slot], A.az[slot]);
-    s.color = dv(A.cx[slot], A.cy[slot], A.cz[slot]);
+__device__ __forceinline__ void load_ray(const RayStream& R, uint32_t p, PathRegs& s) {
+    s.o = dv(R.ox[p], R.oy[p], R.oz[p]);
+    s.d = dv(R.dx[p], R.dy[p], R.dz[p]);
+    s.medium = R.medium[p];
+    s.atten = dv(R.ax[p], R.ay[p], R.az[p]);
 }
-__device__ __forceinline__ void store_ray(const PathArrays& A, int slot, const PathRegs& s) {
-    A.ox[slot] = s.o.x; A.oy[slot] = s.o.y; A.oz[slot] = s.o.z;
-    A.dx[slot] = s.d.x; A.dy[slot] = s.d.y; A.dz[slot] = s.d.z;
-    A.medium[slot] = s.medium;
-    A.ax[slot] = s.atten.x; A.ay[slot] = s.atten.y; A.az[slot] = s.atten.z;
-}
-__device__ __forceinline__ void store_color(const PathArrays& A, int slot, const PathRegs& s) {
-    A.cx[slot] = s.color.x; A.cy[slot] = s.color.y; A.cz[slot] = s.color.z;
+__device__ __forceinline__ void store_ray(const RayStream& R, uint32_t p, const PathRegs& s, uint32_t slot) {
+    R.ox[p] = s.o.x; R.oy[p] = s.o.y; R.oz[p] = s.o.z;
+    R.dx[p] = s.d.x; R.dy[p] = s.d.y; R.dz[p] = s.d.z;
+    R.medium[p] = s.medium;
+    R.ax[p] = s.atten.x; R.ay[p] = s.atten.y; R.az[p] = s.atten.z;
+    R.slot[p] = slot;
 }
 
-// Append to a queue: the wave's survivors take consecutive places behind one atomic.
-// Stands in for thrust::partition over whole path records (reference: src/improved_path_tracer.cu:321-324);
-// here only 4-byte slot indices move.
-__device__ __forceinline__ void wave_append(uint32_t* queue, uint32_t* counter, bool keep, uint32_t value) {
-    uint64_t mask = __ballot(keep);
-    if (mask == 0) return;
-    uint32_t lane = __lane_id();
-    uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    int leader = __ffsll((unsigned long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
-    if (keep) queue[base + before] = value;
-}
-
-// The same for a whole workgroup: one atomic per workgroup and queue.  A single queue counter takes
-// on the order of 10^8 atomics per second however many CUs issue them, so at one atomic per wave
-// the append, not the shading, sets the pace of a kernel; aggregating over CPT_SHADE_BLOCK threads
-// removes that limit.  Must be reached by every thread of the workgroup.  Handles up to three queues
-// at once (keep[k] selects queue k for this thread; at most one may be set).
+// Compaction: positions in the output stream for the threads of a workgroup that keep their path,
+// in thread order, behind one atomic.  A single queue counter takes on the order of 10^8 atomics
+// per second however many CUs issue them; at one atomic per wave that limit, not the shading, set
+// the pace of the kernel, so the count is aggregated over the whole workgroup first.
+// Stands in for thrust::partition over whole path records (reference: src/improved_path_tracer.cu:321-324).
+// Must be reached by every thread of the workgroup; returns the position (valid when keep).
 #define CPT_SHADE_BLOCK 512
 #define CPT_SHADE_WAVES (CPT_SHADE_BLOCK / CPT_WAVE)
-template <int NQ>
-__device__ __forceinline__ void block_append(uint32_t* const (&queue)[NQ], uint32_t* const (&counter)[NQ], const bool (&keep)[NQ],
-                                             uint32_t value) {
-    __shared__ uint32_t s_off[NQ][CPT_SHADE_WAVES];
-    __shared__ uint32_t s_base[NQ];
+__device__ __forceinline__ uint32_t block_claim(uint32_t* counter, bool keep) {
+    __shared__ uint32_t s_off[CPT_SHADE_WAVES];
+    __shared__ uint32_t s_base;
     const uint32_t lane = threadIdx.x & (CPT_WAVE - 1), wave = threadIdx.x / CPT_WAVE;
-    uint64_t mask[NQ];
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-        mask[k] = __ballot(keep[k]);
-        if (lane == 0) s_off[k][wave] = (uint32_t)__popcll(mask[k]);
-    }
+    const uint64_t mask = __ballot(keep);
+    if (lane == 0) s_off[wave] = (uint32_t)__popcll(mask);
     __syncthreads();
-    if (threadIdx.x < NQ) {
-        const int k = (int)threadIdx.x;
+    if (threadIdx.x == 0) {
         uint32_t total = 0;
         for (int w = 0; w < CPT_SHADE_WAVES; ++w) {
-            uint32_t c = s_off[k][w];
-            s_off[k][w] = total;
+            uint32_t c = s_off[w];
+            s_off[w] = total;
             total += c;
         }
-        s_base[k] = total ? atomicAdd(counter[k], total) : 0u;
+        s_base = total ? atomicAdd(counter, total) : 0u;
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NQ; ++k)
-        if (keep[k]) queue[k][s_base[k] + s_off[k][wave] + (uint32_t)__popcll(mask[k] & ((1ull << lane) - 1ull))] = value;
+    uint32_t pos = s_base + s_off[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     __syncthreads();
+    return pos;
 }
 
 // ---- generate ----------------------------------------------------------------------------
-// One thread per slot of the batch: slot = k * n_pix_slots + pixel slot, sample = batch_s0 + k.
-// Every slot gets a ray and the first bounce's queue is simply 0, 1, 2, ...: slots that have no
-// pixel (image sides that are not multiples of 8) or whose path ends before its first segment get
-// a ray that starts far outside the scene and leaves after one node, and are never resolved.
+// One thread per slot of the batch: slot = k * n_pix_slots + pixel slot, sample = batch_s0 + k, and
+// the ray goes to stream position `slot`.  Every slot gets a ray: slots that have no pixel (image
+// sides that are not multiples of 8) or whose path ends before its first segment get a ray that
+// starts far outside the scene and leaves after one node, and are never resolved.
 // reference: initRays (src/improved_path_tracer.cu:221-251)
-__global__ void __launch_bounds__(CPT_BLOCK) k_generate(DScene sc, DParams P, PathArrays A, int batch_s0, int batch_n) {
+__global__ void __launch_bounds__(CPT_BLOCK) k_generate(DScene sc, DParams P, RayStream out, Radiance col, int batch_s0,
+                                                        int batch_n) {
     int total = batch_n * P.n_pix_slots;
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += gridDim.x * blockDim.x) {
         int k = slot / P.n_pix_slots, ps = slot - k * P.n_pix_slots;
         int i, j;
         bool live = slot_to_pixel(P, ps, i, j);
         PathRegs s;
-        s.color = dv(0, 0, 0);
         s.medium = 1.0;
         s.atten = dv(1, 1, 1);
         if (live) {
@@ -117,28 +93,23 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_generate(DScene sc, DParams P, Pa
             s.d = dv(1, 0, 0);
             s.atten = dv(0, 0, 0);
         }
-        store_ray(A, slot, s);
-        store_color(A, slot, s);
+        store_ray(out, (uint32_t)slot, s, (uint32_t)slot);
+        col.cx[slot] = 0.0; col.cy[slot] = 0.0; col.cz[slot] = 0.0;
     }
 }
 
-__global__ void k_iota(uint32_t* q, uint32_t n) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) q[i] = i;
-}
-
 // ---- extend --------------------------------------------------------------------------------
-// Closest hit for every slot in the live queue.
+// Closest hit for every ray of the stream, one ray per thread.
 // reference: the intersection half of pathTrace (src/improved_path_tracer.cu:56-76)
 template <bool COUNT>
-__global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, PathArrays A, const uint32_t* __restrict__ queue,
+__global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, HitBuf hit,
                                                       const uint32_t* __restrict__ counter, unsigned long long* work) {
     CPT_DECLARE_STACK
     uint32_t n = *counter;
     unsigned long long steps = 0, tris = 0;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
-        int slot = (int)queue[q];
-        dvec3 o = dv(A.ox[slot], A.oy[slot], A.oz[slot]);
-        dvec3 d = dv(A.dx[slot], A.dy[slot], A.dz[slot]);
+        dvec3 o = dv(in.ox[q], in.oy[q], in.oz[q]);
+        dvec3 d = dv(in.dx[q], in.dy[q], in.dz[q]);
         double t;
         int tri;
         if (COUNT) {
@@ -149,8 +120,8 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, PathArrays A, c
         } else {
             traverse<false>(sc, o, d, my_stack, t, tri, nullptr);
         }
-        A.hit_t[slot] = t;
-        A.hit_tri[slot] = tri;
+        hit.t[q] = t;
+        hit.tri[q] = tri;
     }
     if (COUNT) {
         if (steps) atomicAdd(&work[3], steps);
@@ -214,7 +185,7 @@ __device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, cons
 }
 
 template <bool COUNT>
-__global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, PathArrays A, const uint32_t* __restrict__ queue,
+__global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStream in, HitBuf hit,
                                                               const uint32_t* __restrict__ counter, uint32_t* cursor,
                                                               uint32_t chunk, uint32_t* spill, unsigned long long* work) {
     __shared__ __attribute__((aligned(128))) unsigned char s_cache[CPT_PW_CACHE_RECORDS * 128];
@@ -245,7 +216,8 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, PathArr
     bool drained = false;                   // wave-uniform: the queue has been handed out completely
 
     bool has_ray = false;
-    int node = -1, sp = 0, lp = 0, slot = 0;
+    int node = -1, sp = 0, lp = 0;
+    uint32_t pos = 0;  // stream position of this lane's ray
     dvec3 o = dv(0, 0, 0), d = dv(0, 0, 1), rinv = dv(0, 0, 1);
     bool exact_only = false;
     double best_t = -1.0;
@@ -270,9 +242,9 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, PathArr
             uint32_t take = want < avail ? want : avail;
             uint32_t mine = (uint32_t)__popcll(idle & lanes_below);
             if (!has_ray && mine < take) {
-                slot = (int)queue[chunk_pos + mine];
-                o = dv(A.ox[slot], A.oy[slot], A.oz[slot]);
-                d = dv(A.dx[slot], A.dy[slot], A.dz[slot]);
+                pos = chunk_pos + mine;  // idle lanes take consecutive positions: one contiguous run per refill
+                o = dv(in.ox[pos], in.oy[pos], in.oz[pos]);
+                d = dv(in.dx[pos], in.dy[pos], in.dz[pos]);
                 rinv = dv(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
                 exact_only = !(fabs(rinv.x) < 1e300 && fabs(rinv.y) < 1e300 && fabs(rinv.z) < 1e300);
                 best_t = -1.0;
@@ -351,8 +323,8 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, PathArr
 
         // ---- retire ----
         if (has_ray && node < 0 && lp == 0) {
-            A.hit_t[slot] = best_t;
-            A.hit_tri[slot] = best_tri;
+            hit.t[pos] = best_t;
+            hit.tri[pos] = best_tri;
             has_ray = false;
         }
     }
@@ -365,36 +337,41 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, PathArr
 // ---- shade + compact -------------------------------------------------------------------------
 // reference: the shading half of pathTrace (src/improved_path_tracer.cu:77-215)
 template <bool COUNT>
-__global__ void __launch_bounds__(CPT_SHADE_BLOCK) k_shade(DScene sc, DParams P, PathArrays A, int batch_s0, int bounce,
-                                                     const uint32_t* __restrict__ queue_in,
-                                                     const uint32_t* __restrict__ counter_in, uint32_t* queue_out,
-                                                     uint32_t* counter_out, unsigned long long* work) {
+__global__ void __launch_bounds__(CPT_SHADE_BLOCK) k_shade(DScene sc, DParams P, RayStream in, HitBuf hit, RayStream out,
+                                                           Radiance col, int batch_s0, int bounce,
+                                                           const uint32_t* __restrict__ counter_in, uint32_t* counter_out,
+                                                           unsigned long long* work) {
     uint32_t n = *counter_in;
-    uint32_t n_round = (n + CPT_SHADE_BLOCK - 1) / CPT_SHADE_BLOCK * CPT_SHADE_BLOCK;  // whole workgroups reach block_append together
+    uint32_t n_round = (n + CPT_SHADE_BLOCK - 1) / CPT_SHADE_BLOCK * CPT_SHADE_BLOCK;  // whole workgroups reach block_claim together
     unsigned long long hits = 0, segs = 0;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_round; q += gridDim.x * blockDim.x) {
         bool go = false;
-        int slot = 0;
+        uint32_t slot = 0;
+        PathRegs s;
         if (q < n) {
-            slot = (int)queue_in[q];
-            int k = slot / P.n_pix_slots, ps = slot - k * P.n_pix_slots;
-            int i, j;
-            slot_to_pixel(P, ps, i, j);
-            uint32_t pixel = (uint32_t)(i + j * P.w), sample = (uint32_t)(batch_s0 + k);
-            PathRegs s;
-            load_path(A, slot, s);
-            double t = A.hit_t[slot];
-            int tri = A.hit_tri[slot];
+            int tri = hit.tri[q];
             if (COUNT) { segs++; hits += (tri >= 0); }
-            go = shade_bounce(sc, P, pixel, sample, bounce, t, tri, s);
-            if (go) go = roulette(P, pixel, sample, bounce + 1, s);
-            if (go) store_ray(A, slot, s);
-            store_color(A, slot, s);
+            if (tri >= 0) {
+                slot = in.slot[q];
+                int k = (int)slot / P.n_pix_slots, ps = (int)slot - k * P.n_pix_slots;
+                int i, j;
+                slot_to_pixel(P, ps, i, j);
+                uint32_t pixel = (uint32_t)(i + j * P.w), sample = (uint32_t)(batch_s0 + k);
+                load_ray(in, q, s);
+                double t = hit.t[q];
+                dvec3 emitted;
+                int lobe = choose_lobe(sc, P, pixel, sample, bounce, tri, s.atten, emitted);
+                if (emitted.x != 0.0 || emitted.y != 0.0 || emitted.z != 0.0) {  // adding zero changes nothing: skip the round trip
+                    col.cx[slot] += emitted.x; col.cy[slot] += emitted.y; col.cz[slot] += emitted.z;
+                }
+                if (lobe != CPT_LOBE_NONE) {
+                    scatter(lobe, sc, P, pixel, sample, bounce, t, tri, s);
+                    go = roulette(P, pixel, sample, bounce + 1, s);
+                }
+            }
         }
-        uint32_t* const qs[1] = {queue_out};
-        uint32_t* const cs[1] = {counter_out};
-        const bool ks[1] = {go};
-        block_append<1>(qs, cs, ks, (uint32_t)slot);
+        uint32_t p = block_claim(counter_out, go);
+        if (go) store_ray(out, p, s, slot);
     }
     if (COUNT) {
         if (segs) atomicAdd(&work[1], segs);
@@ -402,100 +379,18 @@ __global__ void __launch_bounds__(CPT_SHADE_BLOCK) k_shade(DScene sc, DParams P,
     }
 }
 
-// ---- shade, split by lobe ---------------------------------------------------------------------------
-// The single shade kernel runs three very different scatter routines under one roof, and a wave
-// whose lanes chose different lobes pays for all of them.  Split form: k_select does what every hit
-// needs (emission, termination, lobe choice) and sorts the surviving slots into one queue per lobe;
-// k_scatter<LOBE> then runs one routine over its own queue with every lane doing the same thing, and
-// appends to the next bounce's queue (which so arrives grouped by lobe).
-__global__ void __launch_bounds__(CPT_SHADE_BLOCK) k_select(DScene sc, DParams P, PathArrays A, int batch_s0, int bounce,
-                                                      const uint32_t* __restrict__ queue_in,
-                                                      const uint32_t* __restrict__ counter_in, uint32_t* lobe_queues,
-                                                      size_t lobe_stride, uint32_t* lobe_counters,
-                                                      unsigned long long* work) {
-    uint32_t n = *counter_in;
-    uint32_t n_round = (n + CPT_SHADE_BLOCK - 1) / CPT_SHADE_BLOCK * CPT_SHADE_BLOCK;
-    unsigned long long hits = 0, segs = 0;
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_round; q += gridDim.x * blockDim.x) {
-        int lobe = CPT_LOBE_NONE;
-        int slot = 0;
-        if (q < n) {
-            slot = (int)queue_in[q];
-            int tri = A.hit_tri[slot];
-            if (work) { segs++; hits += (tri >= 0); }
-            if (tri >= 0) {
-                int k = slot / P.n_pix_slots, ps = slot - k * P.n_pix_slots;
-                int i, j;
-                slot_to_pixel(P, ps, i, j);
-                dvec3 atten = dv(A.ax[slot], A.ay[slot], A.az[slot]);
-                dvec3 color = dv(A.cx[slot], A.cy[slot], A.cz[slot]);
-                dvec3 before = color;
-                lobe = choose_lobe(sc, P, (uint32_t)(i + j * P.w), (uint32_t)(batch_s0 + k), bounce, tri, atten, color);
-                if (color.x != before.x || color.y != before.y || color.z != before.z) {
-                    A.cx[slot] = color.x; A.cy[slot] = color.y; A.cz[slot] = color.z;
-                }
-            }
-        }
-        uint32_t* const qs[3] = {lobe_queues, lobe_queues + lobe_stride, lobe_queues + 2 * lobe_stride};
-        uint32_t* const cs[3] = {lobe_counters, lobe_counters + 1, lobe_counters + 2};
-        const bool ks[3] = {lobe == CPT_LOBE_DIFFUSE, lobe == CPT_LOBE_MIRROR, lobe == CPT_LOBE_DIELECTRIC};
-        block_append<3>(qs, cs, ks, (uint32_t)slot);
-    }
-    if (work) {
-        if (segs) atomicAdd(&work[1], segs);
-        if (hits) atomicAdd(&work[2], hits);
-    }
-}
-
-template <int LOBE>
-__global__ void __launch_bounds__(CPT_SHADE_BLOCK) k_scatter(DScene sc, DParams P, PathArrays A, int batch_s0, int bounce,
-                                                       const uint32_t* __restrict__ queue_in,
-                                                       const uint32_t* __restrict__ counter_in, uint32_t* queue_out,
-                                                       uint32_t* counter_out) {
-    uint32_t n = *counter_in;
-    uint32_t n_round = (n + CPT_SHADE_BLOCK - 1) / CPT_SHADE_BLOCK * CPT_SHADE_BLOCK;
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_round; q += gridDim.x * blockDim.x) {
-        bool go = false;
-        int slot = 0;
-        if (q < n) {
-            slot = (int)queue_in[q];
-            int k = slot / P.n_pix_slots, ps = slot - k * P.n_pix_slots;
-            int i, j;
-            slot_to_pixel(P, ps, i, j);
-            uint32_t pixel = (uint32_t)(i + j * P.w), sample = (uint32_t)(batch_s0 + k);
-            PathRegs s;
-            s.o = dv(A.ox[slot], A.oy[slot], A.oz[slot]);
-            s.d = dv(A.dx[slot], A.dy[slot], A.dz[slot]);
-            s.medium = A.medium[slot];
-            s.atten = dv(A.ax[slot], A.ay[slot], A.az[slot]);
-            s.color = dv(0, 0, 0);
-            double t = A.hit_t[slot];
-            int tri = A.hit_tri[slot];
-            if (LOBE == CPT_LOBE_DIFFUSE) scatter_diffuse(sc, P, pixel, sample, bounce, t, tri, s);
-            else if (LOBE == CPT_LOBE_MIRROR) scatter_mirror(sc, t, tri, s);
-            else scatter_dielectric(sc, P, pixel, sample, bounce, t, tri, s);
-            go = roulette(P, pixel, sample, bounce + 1, s);
-            if (go) store_ray(A, slot, s);
-        }
-        uint32_t* const qs[1] = {queue_out};
-        uint32_t* const cs[1] = {counter_out};
-        const bool ks[1] = {go};
-        block_append<1>(qs, cs, ks, (uint32_t)slot);
-    }
-}
-
 // ---- resolve ---------------------------------------------------------------------------------
-// accum[pixel] += color of sample batch_s0, then batch_s0 + 1, ... : the order pathTraceKernel sums
+// accum[pixel] += radiance of sample batch_s0, then batch_s0 + 1, ... : the order pathTraceKernel sums
 // its samples in (reference: src/path_tracer.cu:419-435).
-__global__ void __launch_bounds__(CPT_BLOCK) k_resolve(DParams P, PathArrays A, int batch_n, double* __restrict__ accum) {
+__global__ void __launch_bounds__(CPT_BLOCK) k_resolve(DParams P, Radiance col, int batch_n, double* __restrict__ accum) {
     for (int ps = blockIdx.x * blockDim.x + threadIdx.x; ps < P.n_pix_slots; ps += gridDim.x * blockDim.x) {
         int i, j;
         if (!slot_to_pixel(P, ps, i, j)) continue;
         double* px = accum + 3 * (size_t)(i + j * P.w);
         dvec3 sum = dv(px[0], px[1], px[2]);
         for (int k = 0; k < batch_n; ++k) {
-            int slot = k * P.n_pix_slots + ps;
-            sum = sum + dv(A.cx[slot], A.cy[slot], A.cz[slot]);
+            size_t slot = (size_t)k * P.n_pix_slots + ps;
+            sum = sum + dv(col.cx[slot], col.cy[slot], col.cz[slot]);
         }
         px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
     }
@@ -645,57 +540,34 @@ static inline int grid_for(long long n_threads, int max_blocks) {
     return (int)b;
 }
 
-void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int batch_n) {
+void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& out, const Radiance& col,
+                     int batch_s0, int batch_n) {
     int g = grid_for((long long)batch_n * P.n_pix_slots, L.max_blocks);
-    hipLaunchKernelGGL(k_generate, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, A, batch_s0, batch_n);
+    hipLaunchKernelGGL(k_generate, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, out, col, batch_s0, batch_n);
 }
-void launch_iota(const LaunchCfg& L, uint32_t* q, long long n) {
-    int g = grid_for(n, L.max_blocks);
-    hipLaunchKernelGGL(k_iota, dim3(g), dim3(CPT_BLOCK), 0, L.stream, q, (uint32_t)n);
-}
-static inline int shade_grid(long long n_threads, int max_blocks) {
-    long long b = (n_threads + CPT_SHADE_BLOCK - 1) / CPT_SHADE_BLOCK;
-    if (b < 1) b = 1;
-    if (b > max_blocks) b = max_blocks;
-    return (int)b;
-}
-void launch_extend(const LaunchCfg& L, const DScene& sc, const PathArrays& A, const uint32_t* queue, const uint32_t* counter,
+void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
                    long long max_entries, unsigned long long* work) {
     int g = grid_for(max_entries, L.max_blocks);
-    if (work) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, A, queue, counter, work);
-    else hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, A, queue, counter, work);
+    if (work) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, in, hit, counter, work);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, in, hit, counter, work);
 }
-void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const PathArrays& A, const uint32_t* queue, const uint32_t* counter,
-                      uint32_t* cursor, uint32_t* spill, long long max_entries, unsigned long long* work) {
-    (void)max_entries;
+void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
+                      uint32_t* cursor, uint32_t* spill, unsigned long long* work) {
     int g = L.pw_blocks;
-    if (work) hipLaunchKernelGGL(k_extend_pw<true>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, A, queue, counter, cursor, (uint32_t)L.pw_chunk, spill, work);
-    else hipLaunchKernelGGL(k_extend_pw<false>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, A, queue, counter, cursor, (uint32_t)L.pw_chunk, spill, work);
+    if (work) hipLaunchKernelGGL(k_extend_pw<true>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, cursor, (uint32_t)L.pw_chunk, spill, work);
+    else hipLaunchKernelGGL(k_extend_pw<false>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, cursor, (uint32_t)L.pw_chunk, spill, work);
 }
-void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int bounce,
-                  const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* queue_out, uint32_t* counter_out,
-                  long long max_entries, unsigned long long* work) {
-    int g = shade_grid(max_entries, L.max_blocks);
-    if (work) hipLaunchKernelGGL(k_shade<true>, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, queue_out, counter_out, work);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, queue_out, counter_out, work);
+void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& in, const HitBuf& hit,
+                  const RayStream& out, const Radiance& col, int batch_s0, int bounce, const uint32_t* counter_in,
+                  uint32_t* counter_out, long long max_entries, unsigned long long* work) {
+    long long b = (max_entries + CPT_SHADE_BLOCK - 1) / CPT_SHADE_BLOCK;
+    int g = (int)(b < 1 ? 1 : (b > L.max_blocks ? L.max_blocks : b));
+    if (work) hipLaunchKernelGGL(k_shade<true>, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, in, hit, out, col, batch_s0, bounce, counter_in, counter_out, work);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, in, hit, out, col, batch_s0, bounce, counter_in, counter_out, work);
 }
-void launch_select(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int bounce,
-                   const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* lobe_queues, size_t lobe_stride,
-                   uint32_t* lobe_counters, long long max_entries, unsigned long long* work) {
-    int g = shade_grid(max_entries, L.max_blocks);
-    hipLaunchKernelGGL(k_select, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, lobe_queues, lobe_stride, lobe_counters, work);
-}
-void launch_scatter(const LaunchCfg& L, int lobe, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0,
-                    int bounce, const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* queue_out,
-                    uint32_t* counter_out, long long max_entries) {
-    int g = shade_grid(max_entries, L.max_blocks);
-    if (lobe == CPT_LOBE_DIFFUSE) hipLaunchKernelGGL(k_scatter<CPT_LOBE_DIFFUSE>, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, queue_out, counter_out);
-    else if (lobe == CPT_LOBE_MIRROR) hipLaunchKernelGGL(k_scatter<CPT_LOBE_MIRROR>, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, queue_out, counter_out);
-    else hipLaunchKernelGGL(k_scatter<CPT_LOBE_DIELECTRIC>, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, A, batch_s0, bounce, queue_in, counter_in, queue_out, counter_out);
-}
-void launch_resolve(const LaunchCfg& L, const DParams& P, const PathArrays& A, int batch_n, double* accum) {
+void launch_resolve(const LaunchCfg& L, const DParams& P, const Radiance& col, int batch_n, double* accum) {
     int g = grid_for(P.n_pix_slots, L.max_blocks);
-    hipLaunchKernelGGL(k_resolve, dim3(g), dim3(CPT_BLOCK), 0, L.stream, P, A, batch_n, accum);
+    hipLaunchKernelGGL(k_resolve, dim3(g), dim3(CPT_BLOCK), 0, L.stream, P, col, batch_n, accum);
 }
 void launch_megakernel(const LaunchCfg& L, const DScene& sc, const DParams& P, double* accum, unsigned long long* work) {
     int g = grid_for(P.n_pix_slots, 1 << 30);

@@ -24,18 +24,29 @@ struct DParams {  // cpt_render_params plus what the kernels derive from it
 };
 
 
-// Path state of the wavefront pipeline, structure-of-arrays in HBM, one element per slot.
-struct PathArrays {
+// Path state of the wavefront pipeline, structure-of-arrays in HBM.
+//
+// The rays of one bounce form a dense stream indexed by queue position 0 .. count-1: extend reads
+// position p and writes the hit for p, shade reads p and writes the surviving paths, compacted, at
+// consecutive positions of the other stream.  Nothing is gathered through an index; every access
+// is a contiguous run per wave.  `slot` says which path (pixel slot and sample) a position holds.
+struct RayStream {
     double *ox, *oy, *oz;   // ray origin
     double *dx, *dy, *dz;   // ray direction
     double* medium;         // refractive index of the current medium
     double *ax, *ay, *az;   // throughput
-    double *cx, *cy, *cz;   // radiance gathered by the path
-    double* hit_t;          // extend -> shade
-    int* hit_tri;
+    uint32_t* slot;         // path slot = k * n_pix_slots + pixel slot
 };
-#define CPT_PATH_DOUBLES 14  // doubles per slot in PathArrays
-#define CPT_PATH_BYTES (CPT_PATH_DOUBLES * 8 + 4)
+#define CPT_STREAM_DOUBLES 10
+#define CPT_STREAM_BYTES (CPT_STREAM_DOUBLES * 8 + 4)
+struct HitBuf {             // extend -> shade, indexed by queue position
+    double* t;
+    int* tri;
+};
+struct Radiance {           // radiance gathered per path, indexed by slot; touched only at emitters
+    double *cx, *cy, *cz;
+};
+#define CPT_SLOT_BYTES (2 * CPT_STREAM_BYTES + 12 + 24)  // device bytes per path slot of a batch
 
 // traversal stack of the persistent-wave extend kernel: entries in LDS, and the deepest tree it accepts
 #define CPT_PW_STACK_LDS_HOST 16
@@ -49,22 +60,16 @@ struct LaunchCfg {
     int pw_chunk;    // queue entries a wave takes per atomic
 };
 
-void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int batch_n);
-void launch_iota(const LaunchCfg& L, uint32_t* q, long long n);
-void launch_extend(const LaunchCfg& L, const DScene& sc, const PathArrays& A, const uint32_t* queue, const uint32_t* counter,
+void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& out, const Radiance& col,
+                     int batch_s0, int batch_n);
+void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
                    long long max_entries, unsigned long long* work);
-void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const PathArrays& A, const uint32_t* queue, const uint32_t* counter,
-                      uint32_t* cursor, uint32_t* spill, long long max_entries, unsigned long long* work);
-void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int bounce,
-                  const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* queue_out, uint32_t* counter_out,
-                  long long max_entries, unsigned long long* work);
-void launch_select(const LaunchCfg& L, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0, int bounce,
-                   const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* lobe_queues, size_t lobe_stride,
-                   uint32_t* lobe_counters, long long max_entries, unsigned long long* work);
-void launch_scatter(const LaunchCfg& L, int lobe, const DScene& sc, const DParams& P, const PathArrays& A, int batch_s0,
-                    int bounce, const uint32_t* queue_in, const uint32_t* counter_in, uint32_t* queue_out,
-                    uint32_t* counter_out, long long max_entries);
-void launch_resolve(const LaunchCfg& L, const DParams& P, const PathArrays& A, int batch_n, double* accum);
+void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
+                      uint32_t* cursor, uint32_t* spill, unsigned long long* work);
+void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& in, const HitBuf& hit,
+                  const RayStream& out, const Radiance& col, int batch_s0, int bounce, const uint32_t* counter_in,
+                  uint32_t* counter_out, long long max_entries, unsigned long long* work);
+void launch_resolve(const LaunchCfg& L, const DParams& P, const Radiance& col, int batch_n, double* accum);
 void launch_megakernel(const LaunchCfg& L, const DScene& sc, const DParams& P, double* accum, unsigned long long* work);
 void launch_tonemap(const LaunchCfg& L, const double* accum, int n_values, int spp, uint8_t* rgb);
 void launch_trace_rays(const LaunchCfg& L, const DScene& sc, int n, const double* o3, const double* d3, int* tri, double* t,

@@ -137,7 +137,6 @@ int cpt_set_stream(cpt_ctx* ctx, void* hip_stream);
 /* Tuning knobs, by name: "batch_paths" (path slots the wavefront pipeline keeps in flight,
  * default 2^23), "max_blocks" (grid cap of the grid-stride kernels, default 8 per CU),
  * "extend_variant" (1: persistent waves with an LDS record cache, default; 0: one ray per thread),
- * "shade_variant" (0: one shade kernel, default; 1: lobe-sorted select + scatter kernels),
  * "pw_blocks" / "pw_chunk" (workgroups of the persistent extend kernel / rays claimed per atomic). */
 int cpt_set_option(cpt_ctx* ctx, const char* key, long long value);
 /* Turn per-launch HIP-event timing and device-side work counters on or off (both default off). */
