@@ -62,32 +62,52 @@ __device__ __forceinline__ bool slab_hit(double lx, double ly, double lz, double
 
 // The same verdict as slab_hit, usually without dividing.  With r = 1/d rounded once per ray,
 // a = (plane - o) * r differs from the reference's rounded quotient t = (plane - o) / d by at most
-// 3.1 ulp of a.  The reference's verdict is "every axis' near t <= every axis' far t, and the
-// smallest far t >= 1e-12"; on one axis near <= far always holds (rounding is monotonic), so only
-// the six cross-axis orderings and the epsilon test decide.  When every one of those comparisons
-// is further from equality than the error bound, the verdict computed from the products is the
-// reference's verdict; otherwise `sure` is false and the caller redoes the box with slab_hit.
-// Subnormal, infinite or NaN intermediates end up as "not sure"; the caller must not use this test
-// at all for a ray with a zero direction component (the reference skips such an axis).
+// 3.1 ulp of a (the subtraction is the reference's own, so there is no absolute error term and
+// rays that start on a box plane are decided like any other).
+//
+// The reference's verdict is "every axis' near t <= every axis' far t, and the smallest far t is
+// >= 1e-12" (its early returns can never be undone by a later axis).  On one axis near <= far always
+// holds because rounding is monotonic, and a box that is flat on an axis has near == far there, so
+// only the six cross-axis orderings may be judged by their distance from equality:
+//   G = min over axes k of (far_k - largest near of the other two axes).
+// With TN the largest near and TF the smallest far product and M = 2e-15 (|TF| + |TN|) + 1e-300:
+//   hit   is certain when  G >  M  and TF > 1e-12 (1 + 1e-15)
+//   miss  is certain when  G < -M  or  TF < 1e-12 (1 - 1e-15)
+// One margin serves all six orderings: every near is <= TN and every far is >= TF; once TF > 0
+// (else the epsilon test alone says miss) an ordering far_k - near_i with near_i <= 0 holds with
+// room |far_k| + |near_i|, and one with 0 < near_i <= TN that clears 2e-15 TN = 18 ulp of near_i
+// clears its own 3.1 ulp (|far_k| + |near_i|) bound; symmetrically for a violated ordering.  The
+// floor covers the subnormal range.  Anything else is "not sure" and the caller redoes the box with
+// slab_hit.  Infinite intermediates end up as "not sure"; the caller must not use this test at all
+// for a ray with a zero direction component (the reference skips such an axis, which the products
+// cannot express).
+struct SlabRay {
+    dvec3 r;          // 1/d
+    bool exact_only;  // the products cannot stand in for this ray's quotients at all
+};
+__device__ __forceinline__ SlabRay slab_prepare(const dvec3& o, const dvec3& d) {
+    SlabRay s;
+    s.r = dv(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    // also rules out NaN products: box planes are finite (checked at upload), so a product can only
+    // be NaN through an infinite reciprocal or a non-finite origin
+    s.exact_only = !(fabs(s.r.x) < 1e300 && fabs(s.r.y) < 1e300 && fabs(s.r.z) < 1e300 &&
+                     fabs(o.x) < 1e300 && fabs(o.y) < 1e300 && fabs(o.z) < 1e300);
+    return s;
+}
 __device__ __forceinline__ bool slab_filtered(double lx, double ly, double lz, double hx, double hy, double hz,
-                                              const dvec3& o, const dvec3& r, bool& sure) {
-    double x1 = (lx - o.x) * r.x, x2 = (hx - o.x) * r.x;
-    double y1 = (ly - o.y) * r.y, y2 = (hy - o.y) * r.y;
-    double z1 = (lz - o.z) * r.z, z2 = (hz - o.z) * r.z;
+                                              const dvec3& o, const SlabRay& s, bool& sure) {
+    double x1 = (lx - o.x) * s.r.x, x2 = (hx - o.x) * s.r.x;
+    double y1 = (ly - o.y) * s.r.y, y2 = (hy - o.y) * s.r.y;
+    double z1 = (lz - o.z) * s.r.z, z2 = (hz - o.z) * s.r.z;
     double nx = fmin(x1, x2), fx = fmax(x1, x2);
     double ny = fmin(y1, y2), fy = fmax(y1, y2);
     double nz = fmin(z1, z2), fz = fmax(z1, z2);
-    double cx = fmax(ny, nz), cy = fmax(nx, nz), cz = fmax(nx, ny);  // largest near t of the other two axes
-    double gx = fx - cx, gy = fy - cy, gz = fz - cz;
-    const double k = 1e-15, tiny = 1e-300;  // 9 ulp relative, plus an absolute floor for the subnormal range
-    double mx = (fabs(fx) + fabs(cx)) * k + tiny, my = (fabs(fy) + fabs(cy)) * k + tiny, mz = (fabs(fz) + fabs(cz)) * k + tiny;
-    double far_min = fmin(fx, fmin(fy, fz));
-    bool order_yes = (gx > mx) && (gy > my) && (gz > mz);
-    bool order_no = (gx < -mx) || (gy < -my) || (gz < -mz);
-    bool eps_yes = far_min > 1.000000000000001e-12;
-    bool eps_no = far_min < 0.999999999999999e-12;
-    bool hit = order_yes && eps_yes;
-    sure = hit || order_no || eps_no;
+    double cx = fmax(ny, nz), cy = fmax(nx, nz), cz = fmax(nx, ny);
+    double tn = fmax(cz, nz), tf = fmin(fx, fmin(fy, fz));
+    double g = fmin(fx - cx, fmin(fy - cy, fz - cz));
+    double m = fma(fabs(tf) + fabs(tn), 2e-15, 1e-300);
+    bool hit = (g > m) && (tf > 1.000000000000001e-12);
+    sure = hit || (g < -m) || (tf < 0.999999999999999e-12);
     return hit;
 }
 
@@ -146,18 +166,15 @@ __device__ __forceinline__ void traverse(const DScene& sc, const dvec3& o, const
     }
     int sp = 0;
     int node = 0;
-    const dvec3 rinv = dv(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-    // A zero direction component makes the reference skip that axis altogether, which the products
-    // cannot express (the reciprocal is infinite): such rays always take the exact test.
-    const bool exact_only = !(fabs(rinv.x) < 1e300 && fabs(rinv.y) < 1e300 && fabs(rinv.z) < 1e300);
+    const SlabRay sr = slab_prepare(o, d);
     for (;;) {
         const double2* p = (const double2*)(sc.nodes + node);
         double2 b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3], b4 = p[4], b5 = p[5];
         int4 refs = ((const int4*)p)[6];  // lref, rref, lid, rid
         bool sure_l, sure_r;
-        bool hl = slab_filtered(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, o, rinv, sure_l);
-        bool hr = slab_filtered(b3.x, b3.y, b4.x, b4.y, b5.x, b5.y, o, rinv, sure_r);
-        if (exact_only || !(sure_l && sure_r)) {  // rare: a comparison too close to call without the exact quotients
+        bool hl = slab_filtered(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, o, sr, sure_l);
+        bool hr = slab_filtered(b3.x, b3.y, b4.x, b4.y, b5.x, b5.y, o, sr, sure_r);
+        if (sr.exact_only || !(sure_l && sure_r)) {  // rare: a comparison too close to call without the exact quotients
             hl = slab_hit(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, o, d);
             hr = slab_hit(b3.x, b3.y, b4.x, b4.y, b5.x, b5.y, o, d);
         }

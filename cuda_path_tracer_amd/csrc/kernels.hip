@@ -153,8 +153,6 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
 #define CPT_PW_STACK_LDS 16
 static_assert(CPT_PW_STACK_LDS == CPT_PW_STACK_LDS_HOST, "stack split must match the spill buffer sizing");
 #define CPT_PW_LEAF_CAP 6     // parked leaves per lane (a node expansion adds at most two)
-#define CPT_PW_REFILL 12      // refill when at least this many lanes are idle
-#define CPT_PW_LEAF_GO 20     // run the triangle phase when at least this many lanes have a parked leaf
 
 struct Rec7 {  // the first seven 16-byte pieces of a 128-byte record
     double2 p0, p1, p2, p3, p4, p5, p6;
@@ -187,7 +185,7 @@ __device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, cons
 template <bool COUNT>
 __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStream in, HitBuf hit,
                                                               const uint32_t* __restrict__ counter, uint32_t* cursor,
-                                                              uint32_t chunk, uint32_t* spill, unsigned long long* work) {
+                                                              uint32_t chunk, uint32_t refill_at, uint32_t leaf_go, uint32_t* spill, unsigned long long* work) {
     __shared__ __attribute__((aligned(128))) unsigned char s_cache[CPT_PW_CACHE_RECORDS * 128];
     __shared__ uint32_t s_nodes[CPT_PW_WAVES][CPT_PW_STACK_LDS][CPT_WAVE];
     __shared__ uint32_t s_leaves[CPT_PW_WAVES][CPT_PW_LEAF_CAP][CPT_WAVE];
@@ -218,17 +216,17 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     bool has_ray = false;
     int node = -1, sp = 0, lp = 0;
     uint32_t pos = 0;  // stream position of this lane's ray
-    dvec3 o = dv(0, 0, 0), d = dv(0, 0, 1), rinv = dv(0, 0, 1);
-    bool exact_only = false;
+    dvec3 o = dv(0, 0, 0), d = dv(0, 0, 1);
+    SlabRay sr = slab_prepare(o, dv(1, 1, 1));
     double best_t = -1.0;
     int best_tri = -1;
     uint32_t best_rank = 0xFFFFFFFFu;
-    unsigned long long steps = 0, tris = 0;
+    unsigned long long steps = 0, tris = 0, exact = 0;
 
     for (;;) {
         // ---- refill idle lanes ----
         uint64_t idle = __ballot(!has_ray);
-        if (!drained && (uint32_t)__popcll(idle) >= CPT_PW_REFILL) {
+        if (!drained && (uint32_t)__popcll(idle) >= refill_at) {
             if (chunk_pos == chunk_end) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(cursor, chunk);
@@ -245,8 +243,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 pos = chunk_pos + mine;  // idle lanes take consecutive positions: one contiguous run per refill
                 o = dv(in.ox[pos], in.oy[pos], in.oz[pos]);
                 d = dv(in.dx[pos], in.dy[pos], in.dz[pos]);
-                rinv = dv(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-                exact_only = !(fabs(rinv.x) < 1e300 && fabs(rinv.y) < 1e300 && fabs(rinv.z) < 1e300);
+                sr = slab_prepare(o, d);
                 best_t = -1.0;
                 best_tri = -1;
                 best_rank = 0xFFFFFFFFu;
@@ -273,9 +270,10 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
             Rec7 r = fetch_record(sc.nodes, cache, 0, cached_nodes, node);
             int2 refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));  // lref, rref
             bool sure_l, sure_r;
-            bool hl = slab_filtered(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, rinv, sure_l);
-            bool hr = slab_filtered(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, rinv, sure_r);
-            if (exact_only || !(sure_l && sure_r)) {
+            bool hl = slab_filtered(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, sr, sure_l);
+            bool hr = slab_filtered(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, sr, sure_r);
+            if (sr.exact_only || !(sure_l && sure_r)) {
+                if (COUNT) exact++;
                 hl = slab_hit(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, d);
                 hr = slab_hit(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, d);
             }
@@ -306,7 +304,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
         if (have_leaf) {
             uint64_t have_node = __ballot(node >= 0);
             uint64_t nearly_full = __ballot(lp > CPT_PW_LEAF_CAP - 2);
-            if ((uint32_t)__popcll(have_leaf) >= CPT_PW_LEAF_GO || have_node == 0 || nearly_full) {
+            if ((uint32_t)__popcll(have_leaf) >= leaf_go || have_node == 0 || nearly_full) {
                 if (lp > 0) {
                     --lp;
                     int tri = (int)my_leaves[lp * CPT_WAVE];
@@ -331,6 +329,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     if (COUNT) {
         if (steps) atomicAdd(&work[3], steps);
         if (tris) atomicAdd(&work[4], tris);
+        if (exact) atomicAdd(&work[5], exact);
     }
 }
 
@@ -554,8 +553,8 @@ void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, co
 void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
                       uint32_t* cursor, uint32_t* spill, unsigned long long* work) {
     int g = L.pw_blocks;
-    if (work) hipLaunchKernelGGL(k_extend_pw<true>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, cursor, (uint32_t)L.pw_chunk, spill, work);
-    else hipLaunchKernelGGL(k_extend_pw<false>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, cursor, (uint32_t)L.pw_chunk, spill, work);
+    if (work) hipLaunchKernelGGL(k_extend_pw<true>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, cursor, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go, spill, work);
+    else hipLaunchKernelGGL(k_extend_pw<false>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, cursor, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go, spill, work);
 }
 void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& in, const HitBuf& hit,
                   const RayStream& out, const Radiance& col, int batch_s0, int bounce, const uint32_t* counter_in,

@@ -58,6 +58,8 @@ struct LaunchCfg {
     int max_blocks;  // grid cap for grid-stride kernels
     int pw_blocks;   // number of persistent 1024-thread workgroups of k_extend_pw (one per CU)
     int pw_chunk;    // queue entries a wave takes per atomic
+    int pw_refill;   // a wave refills when at least this many of its lanes are idle
+    int pw_leaf_go;  // a wave runs its triangle phase when at least this many lanes have a parked leaf
 };
 
 void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& out, const Radiance& col,

@@ -121,6 +121,7 @@ typedef struct cpt_stats {
     uint64_t launches_generate, launches_extend, launches_shade, launches_mega;
     double ms_generate, ms_extend, ms_shade, ms_mega, ms_total; /* HIP-event time on the render stream */
     uint64_t iterations;
+    uint64_t exact_node_steps;  /* node steps whose boxes were re-tested with the reference's divisions */
 } cpt_stats;
 
 typedef struct cpt_ctx cpt_ctx;

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--mode", type=int, default=0)
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--stats", action="store_true", help="time kernels with HIP events and count work")
+    ap.add_argument("--count", action="store_true", help="one extra render with work counters on")
     ap.add_argument("--opt", action="append", default=[], help="key=value passed to cpt_set_option")
     args = ap.parse_args()
     import torch
@@ -51,6 +52,16 @@ def main():
             st = r.stats()
             print("   ms: generate %.2f extend %.2f shade %.2f total %.2f (launches: %d extend)" %
                   (st["ms_generate"], st["ms_extend"], st["ms_shade"], st["ms_total"], st["launches_extend"]), flush=True)
+    if args.count:
+        r.set_instrumentation(time_kernels=False, count_work=True)
+        acc.zero_()
+        r.reset_stats()
+        r.render_into(acc.data_ptr(), p)
+        r.synchronize()
+        st = r.stats()
+        print("   work: segments %d node_steps %d tri_tests %d exact_node_steps %d (%.3f%%)" %
+              (st["segments"], st["node_steps"], st["tri_tests"], st["exact_node_steps"],
+               100.0 * st["exact_node_steps"] / max(1, st["node_steps"])), flush=True)
 
 
 if __name__ == "__main__":
