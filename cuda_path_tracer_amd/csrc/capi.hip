@@ -27,7 +27,7 @@ struct cpt_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string err;
 
-    void *d_nodes = nullptr, *d_tris = nullptr, *d_tnorm = nullptr, *d_mats = nullptr;
+    void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr;
     DScene sc{};
     bool has_scene = false;
     int n_tree_nodes = 0, tree_height = 0;
@@ -75,9 +75,8 @@ static int fail(cpt_ctx* c, int code, const char* fmt, ...) {
 static void free_scene(cpt_ctx* c) {
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_tris) (void)hipFree(c->d_tris);
-    if (c->d_tnorm) (void)hipFree(c->d_tnorm);
-    if (c->d_mats) (void)hipFree(c->d_mats);
-    c->d_nodes = c->d_tris = c->d_tnorm = c->d_mats = nullptr;
+    if (c->d_shade) (void)hipFree(c->d_shade);
+    c->d_nodes = c->d_tris = c->d_shade = nullptr;
     c->has_scene = false;
 }
 static void free_paths(cpt_ctx* c) {
@@ -216,8 +215,7 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     size_t nb = sizeof(cpt_node) * (size_t)std::max(s->n_nodes, 1);
     HIP_TRY(c, hipMalloc(&c->d_nodes, nb));
     HIP_TRY(c, hipMalloc(&c->d_tris, sizeof(cpt_tri) * (size_t)s->n_tris));
-    HIP_TRY(c, hipMalloc(&c->d_tnorm, sizeof(cpt_tri_normals) * (size_t)s->n_tris));
-    HIP_TRY(c, hipMalloc(&c->d_mats, sizeof(cpt_material) * (size_t)s->n_materials));
+    HIP_TRY(c, hipMalloc(&c->d_shade, sizeof(ShadeRec) * (size_t)s->n_tris));
     if (s->n_nodes > 0) HIP_TRY(c, hipMemcpy(c->d_nodes, s->nodes, sizeof(cpt_node) * (size_t)s->n_nodes, hipMemcpyHostToDevice));
     {   // The tie-break rank of a triangle is the position of its leaf's box test in the reference's
         // traversal order: 2 * (expansion order of the parent) + side, where nodes are expanded in
@@ -240,12 +238,30 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
         }
         HIP_TRY(c, hipMemcpy(c->d_tris, tris.data(), sizeof(cpt_tri) * (size_t)s->n_tris, hipMemcpyHostToDevice));
     }
-    HIP_TRY(c, hipMemcpy(c->d_tnorm, s->tri_normals, sizeof(cpt_tri_normals) * (size_t)s->n_tris, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_mats, s->materials, sizeof(cpt_material) * (size_t)s->n_materials, hipMemcpyHostToDevice));
+    {   // one shading record per triangle: geometry, vertex normals and a copy of its material
+        std::vector<ShadeRec> recs((size_t)s->n_tris);
+        for (int i = 0; i < s->n_tris; ++i) {
+            const cpt_tri& t = s->tris[i];
+            const cpt_tri_normals& tn = s->tri_normals[i];
+            const cpt_material& m = s->materials[t.material];
+            ShadeRec& r = recs[(size_t)i];
+            memset(&r, 0, sizeof r);
+            r.tri_flags = t.flags;
+            r.mat_flags = m.flags;
+            const LobeProb pr = lobe_probabilities(m.kd, m.ks, m.kt);
+            r.p_diff = pr.diff; r.p_spec = pr.spec; r.p_trans = pr.trans;
+            r.index = m.index;
+            for (int k = 0; k < 3; ++k) {
+                r.n[k] = t.n[k]; r.a[k] = t.a[k]; r.b[k] = t.b[k]; r.c[k] = t.c[k];
+                r.na[k] = tn.na[k]; r.nb[k] = tn.nb[k]; r.nc[k] = tn.nc[k];
+                r.ke[k] = m.ke[k]; r.kd[k] = m.kd[k]; r.ks[k] = m.ks[k]; r.kr[k] = m.kr[k]; r.kt[k] = m.kt[k];
+            }
+        }
+        HIP_TRY(c, hipMemcpy(c->d_shade, recs.data(), sizeof(ShadeRec) * recs.size(), hipMemcpyHostToDevice));
+    }
     c->sc.nodes = (const cpt_node*)c->d_nodes;
     c->sc.tris = (const cpt_tri*)c->d_tris;
-    c->sc.tnorm = (const cpt_tri_normals*)c->d_tnorm;
-    c->sc.mats = (const cpt_material*)c->d_mats;
+    c->sc.shade = (const ShadeRec*)c->d_shade;
     c->sc.cam = s->camera;
     c->sc.n_nodes = s->n_nodes;
     c->sc.n_tris = s->n_tris;

@@ -223,10 +223,9 @@ __device__ __forceinline__ void traverse(const DScene& sc, const dvec3& o, const
 // Shading normal of a hit (reference: src/gpu/GPUTrimesh.cuh:91-108).  The reference computes the
 // barycentric weights inside every triangle test; only the winning hit's are ever used, so they
 // are computed once here from the same expressions.
-__device__ __forceinline__ dvec3 shading_normal(const DScene& sc, int tri, const dvec3& o, const dvec3& d, double t) {
-    const cpt_tri* tp = sc.tris + tri;
+__device__ __forceinline__ dvec3 shading_normal(const ShadeRec* tp, const dvec3& o, const dvec3& d, double t) {
     dvec3 n = dv(tp->n);
-    if (!(tp->flags & CPT_TRI_VERTEX_NORMALS)) return normalize(n);
+    if (!(tp->tri_flags & CPT_TRI_VERTEX_NORMALS)) return normalize(n);
     dvec3 a = dv(tp->a), b = dv(tp->b), c = dv(tp->c);
     dvec3 P = o + d * t;
     double alpha = length(cross(b - P, c - P));
@@ -234,8 +233,7 @@ __device__ __forceinline__ dvec3 shading_normal(const DScene& sc, int tri, const
     double denom = length(cross(b - a, c - a));
     alpha /= denom;
     beta /= denom;
-    const cpt_tri_normals* tn = sc.tnorm + tri;
-    return normalize(alpha * dv(tn->na) + beta * dv(tn->nb) + (1 - alpha - beta) * dv(tn->nc));
+    return normalize(alpha * dv(tp->na) + beta * dv(tp->nb) + (1 - alpha - beta) * dv(tp->nc));
 }
 
 // ---- counter RNG -----------------------------------------------------------------------
@@ -348,23 +346,6 @@ __device__ __forceinline__ bool roulette(const DParams& P, uint32_t pixel, uint3
 #define CPT_LOBE_MIRROR 1
 #define CPT_LOBE_DIELECTRIC 2
 
-struct LobeProb {
-    double diff, spec, trans;
-};
-// reference: src/path_tracer.cu:272-279
-__device__ __forceinline__ LobeProb lobe_probabilities(const cpt_material* m) {
-    dvec3 kd = dv(m->kd), ks = dv(m->ks), kt = dv(m->kt);
-    double spec = (ks.x + ks.y + ks.z) / 3.0;
-    double diff = (kd.x + kd.y + kd.z) / 3.0;
-    double trans = (kt.x + kt.y + kt.z) / 3.0;
-    double total = spec + diff + trans;
-    LobeProb p;
-    p.diff = diff / total;
-    p.spec = spec / total;
-    p.trans = trans / total;
-    return p;
-}
-
 // Emission and lobe choice for a hit on triangle `tri` (tri < 0: the ray missed).  `emitted` receives
 // ke * throughput, which the caller adds to the path's radiance; returns the lobe to scatter with, or
 // CPT_LOBE_NONE when the path ends.
@@ -372,15 +353,14 @@ __device__ __forceinline__ int choose_lobe(const DScene& sc, const DParams& P, u
                                            int tri, const dvec3& atten, dvec3& emitted) {
     emitted = dv(0, 0, 0);
     if (tri < 0) return CPT_LOBE_NONE;  // the reference re-intersects the same missing ray until the loop ends
-    const cpt_material* m = sc.mats + sc.tris[tri].material;
+    const ShadeRec* m = sc.shade + tri;
     emitted = dv(m->ke) * atten;
-    if (!(m->flags & (CPT_MAT_DIFF | CPT_MAT_SPEC | CPT_MAT_TRANS))) return CPT_LOBE_NONE;
+    if (!(m->mat_flags & (CPT_MAT_DIFF | CPT_MAT_SPEC | CPT_MAT_TRANS))) return CPT_LOBE_NONE;
     if (bounce >= P.depth) return CPT_LOBE_NONE;  // the new ray would never be traced
-    LobeProb pr = lobe_probabilities(m);
     double prob, unused;
     draw2(P, pixel, sample, (uint32_t)bounce, CPT_STREAM_SELECT, prob, unused);
-    if (prob < pr.diff) return CPT_LOBE_DIFFUSE;
-    if (prob < pr.diff + pr.spec) return CPT_LOBE_MIRROR;
+    if (prob < m->p_diff) return CPT_LOBE_DIFFUSE;
+    if (prob < m->p_diff + m->p_spec) return CPT_LOBE_MIRROR;
     return CPT_LOBE_DIELECTRIC;
 }
 
@@ -394,9 +374,10 @@ __device__ __forceinline__ int choose_lobe(const DScene& sc, const DParams& P, u
 // writes them).
 __device__ __forceinline__ void scatter(int lobe, const DScene& sc, const DParams& P, uint32_t pixel, uint32_t sample,
                                         int bounce, double t, int tri, PathRegs& s) {
-    const cpt_material* m = sc.mats + sc.tris[tri].material;
-    const LobeProb pr = lobe_probabilities(m);
-    const dvec3 N = shading_normal(sc, tri, s.o, s.d, t);
+    const ShadeRec* m = sc.shade + tri;
+    LobeProb pr;
+    pr.diff = m->p_diff; pr.spec = m->p_spec; pr.trans = m->p_trans;
+    const dvec3 N = shading_normal(m, s.o, s.d, t);
     const dvec3 at = s.o + (t * s.d);
 
     bool reflects = false;        // ends in the reflection block below

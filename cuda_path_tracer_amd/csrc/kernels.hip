@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
 // ---- shade + compact -------------------------------------------------------------------------
 // reference: the shading half of pathTrace (src/improved_path_tracer.cu:77-215)
 template <bool COUNT>
-__global__ void __launch_bounds__(CPT_SHADE_BLOCK) k_shade(DScene sc, DParams P, RayStream in, HitBuf hit, RayStream out,
+__global__ void __launch_bounds__(CPT_SHADE_BLOCK, 4) k_shade(DScene sc, DParams P, RayStream in, HitBuf hit, RayStream out,
                                                            Radiance col, int batch_s0, int bounce,
                                                            const uint32_t* __restrict__ counter_in, uint32_t* counter_out,
                                                            unsigned long long* work) {
@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_trace_rays(DScene sc, int n, cons
         tri_out[r] = tri;
         t_out[r] = t;
         if (normal_out) {
-            dvec3 N = tri >= 0 ? shading_normal(sc, tri, o, d, t) : dv(0, 0, 0);
+            dvec3 N = tri >= 0 ? shading_normal(sc.shade + tri, o, d, t) : dv(0, 0, 0);
             normal_out[3 * (size_t)r] = N.x; normal_out[3 * (size_t)r + 1] = N.y; normal_out[3 * (size_t)r + 2] = N.z;
         }
         if (vhash_out) vhash_out[r] = rec.visit_hash;

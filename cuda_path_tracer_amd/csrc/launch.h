@@ -4,12 +4,48 @@
 #include <stdint.h>
 
 #include "cpt_amd.h"
+#include "dvec.h"
+
+// Everything the shading half of a bounce needs to know about a triangle, in one record, so a hit
+// costs one dependent fetch (hit -> record) instead of a chain (hit -> triangle -> material, plus the
+// vertex normals).  The first 128 bytes serve a flat-shaded diffuse hit on their own.  The lobe
+// probabilities depend on the material alone and are computed once, at upload, with the
+// reference's expressions (src/path_tracer.cu:272-279).
+struct __attribute__((aligned(128))) ShadeRec {
+    uint32_t tri_flags, mat_flags;     // CPT_TRI_*, CPT_MAT_*
+    double n[3];                       // face normal as stored with the triangle
+    double ke[3], kd[3];
+    double p_diff, p_spec, p_trans;    // lobe probabilities
+    double index;
+    double pad0[2];
+    double ks[3], kr[3], kt[3];        // second 128 bytes: specular / transmissive materials
+    double a[3], b[3], c[3];           // vertices and vertex normals: smooth-shaded triangles only
+    double na[3], nb[3], nc[3];
+    double pad1[5];
+};
+static_assert(sizeof(ShadeRec) == 384, "ShadeRec is three 128-byte lines");
+
+struct LobeProb {
+    double diff, spec, trans;
+};
+// reference: src/path_tracer.cu:272-279.  Evaluated on the host when a scene is uploaded; a
+// material's probabilities are the same at every hit.
+CPT_HD LobeProb lobe_probabilities(const double* kd3, const double* ks3, const double* kt3) {
+    double spec = (ks3[0] + ks3[1] + ks3[2]) / 3.0;
+    double diff = (kd3[0] + kd3[1] + kd3[2]) / 3.0;
+    double trans = (kt3[0] + kt3[1] + kt3[2]) / 3.0;
+    double total = spec + diff + trans;
+    LobeProb p;
+    p.diff = diff / total;
+    p.spec = spec / total;
+    p.trans = trans / total;
+    return p;
+}
 
 struct DScene {
     const cpt_node* __restrict__ nodes;
-    const cpt_tri* __restrict__ tris;
-    const cpt_tri_normals* __restrict__ tnorm;
-    const cpt_material* __restrict__ mats;
+    const cpt_tri* __restrict__ tris;       // intersection records (extend)
+    const ShadeRec* __restrict__ shade;     // shading records (shade), one per triangle
     cpt_camera cam;
     int n_nodes, n_tris;
 };
