@@ -62,7 +62,8 @@ class Stats(C.Structure):
                 ("tri_tests", C.c_uint64), ("launches_generate", C.c_uint64), ("launches_extend", C.c_uint64),
                 ("launches_shade", C.c_uint64), ("launches_mega", C.c_uint64), ("ms_generate", C.c_double),
                 ("ms_extend", C.c_double), ("ms_shade", C.c_double), ("ms_mega", C.c_double), ("ms_total", C.c_double),
-                ("iterations", C.c_uint64), ("exact_node_steps", C.c_uint64)]
+                ("iterations", C.c_uint64), ("exact_node_steps", C.c_uint64), ("box_passes", C.c_uint64),
+                ("leaf_passes", C.c_uint64)]
 
 
 assert C.sizeof(Node) == 128 and C.sizeof(Tri) == 128 and C.sizeof(TriNormals) == 72 and C.sizeof(Material) == 136

@@ -50,7 +50,7 @@ struct cpt_ctx {
     long long batch_paths = 1 << 23;  // path slots kept in flight by the wavefront pipeline
     int pw_blocks = 0;             // persistent workgroups of the extend kernel (one per CU)
     int pw_chunk = 256;            // queue entries a persistent wave takes per atomic
-    int pw_refill = 12, pw_leaf_go = 32;
+    int pw_refill = 12, pw_leaf_go = 32, pw_full_go = 1;
     int extend_variant = 1;        // 0: one ray per thread; 1: persistent waves with refill
 };
 
@@ -158,6 +158,9 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
     } else if (!strcmp(key, "pw_refill")) {
         if (value < 1 || value > 64) return fail(c, CPT_EINVAL, "pw_refill must be in [1, 64]");
         c->pw_refill = (int)value;
+    } else if (!strcmp(key, "pw_full_go")) {
+        if (value < 1 || value > 64) return fail(c, CPT_EINVAL, "pw_full_go must be in [1, 64]");
+        c->pw_full_go = (int)value;
     } else if (!strcmp(key, "pw_leaf_go")) {
         if (value < 1 || value > 64) return fail(c, CPT_EINVAL, "pw_leaf_go must be in [1, 64]");
         c->pw_leaf_go = (int)value;
@@ -329,6 +332,8 @@ static int collect_work(cpt_ctx* c) {
     c->stats.node_steps += w[3];
     c->stats.tri_tests += w[4];
     c->stats.exact_node_steps += w[5];
+    c->stats.box_passes += w[6];
+    c->stats.leaf_passes += w[7];
     return CPT_OK;
 }
 
@@ -340,7 +345,7 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
     if (rc != CPT_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     if (P.s1 == P.s0) return CPT_OK;
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
     unsigned long long* work = c->count_work ? c->d_work : nullptr;
     const bool timed = c->time_kernels;
     long long n_paths = (long long)P.w * P.h * (P.s1 - P.s0);
@@ -427,7 +432,7 @@ int cpt_tonemap(cpt_ctx* c, const double* d_accum, int32_t w, int32_t h, int32_t
     if (!c || !d_accum || !d_rgb) return c ? fail(c, CPT_EINVAL, "cpt_tonemap: NULL argument") : CPT_EINVAL;
     if (w < 1 || h < 1 || total_spp < 1) return fail(c, CPT_EINVAL, "cpt_tonemap: bad size or sample count");
     HIP_TRY(c, hipSetDevice(c->device));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
     launch_tonemap(L, d_accum, w * h * 3, total_spp, d_rgb);
     HIP_TRY(c, hipGetLastError());
     return CPT_OK;
@@ -499,7 +504,7 @@ int cpt_trace_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, 
     if (h_bitmap) { HIP_TRY(c, bm.alloc(N * (size_t)stride)); HIP_TRY(c, hipMemsetAsync(bm.p, 0, N * (size_t)stride, c->stream)); }
     HIP_TRY(c, hipMemcpyAsync(o.p, h_o, N * 24, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d.p, h_d, N * 24, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
     launch_trace_rays(L, c->sc, n, (const double*)o.p, (const double*)d.p, (int*)tri.p, (double*)t.p, (double*)nrm.p,
                       (unsigned long long*)vh.p, (int*)cnt.p, h_bitmap ? (uint8_t*)bm.p : nullptr, stride);
     HIP_TRY(c, hipGetLastError());
@@ -520,7 +525,7 @@ int cpt_camera_rays(cpt_ctx* c, int32_t w, int32_t h, double jx, double jy, doub
     size_t N = (size_t)w * h;
     DevBuf o, d;
     HIP_TRY(c, o.alloc(N * 24)); HIP_TRY(c, d.alloc(N * 24));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
     launch_camera_rays(L, c->sc, w, h, jx, jy, (double*)o.p, (double*)d.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_o, o.p, N * 24, hipMemcpyDeviceToHost, c->stream));
@@ -544,7 +549,7 @@ int cpt_path_radiance(cpt_ctx* c, const cpt_render_params* p, int32_t n, const i
     size_t N = (size_t)n;
     HIP_TRY(c, ij.alloc(N * 12)); HIP_TRY(c, rad.alloc(N * 24));
     HIP_TRY(c, hipMemcpyAsync(ij.p, h_ijs, N * 12, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
     launch_path_radiance(L, c->sc, P, n, (const int*)ij.p, (double*)rad.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_rad, rad.p, N * 24, hipMemcpyDeviceToHost, c->stream));
@@ -561,7 +566,7 @@ int cpt_probe_math(cpt_ctx* c, int32_t n, const double* h_a, const double* h_b, 
     HIP_TRY(c, a.alloc(N * 8)); HIP_TRY(c, b.alloc(N * 8)); HIP_TRY(c, s.alloc(N * 8)); HIP_TRY(c, q.alloc(N * 8));
     HIP_TRY(c, hipMemcpyAsync(a.p, h_a, N * 8, hipMemcpyHostToDevice, c->stream));
     if (h_b) HIP_TRY(c, hipMemcpyAsync(b.p, h_b, N * 8, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
     launch_probe_math(L, n, (const double*)a.p, h_b ? (const double*)b.p : nullptr, (double*)s.p, (double*)q.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_sqrt, s.p, N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -575,7 +580,7 @@ int cpt_probe_rng(cpt_ctx* c, const uint32_t ctr[4], const uint32_t key[2], uint
     HIP_TRY(c, hipSetDevice(c->device));
     DevBuf o, u;
     HIP_TRY(c, o.alloc(16)); HIP_TRY(c, u.alloc(16));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
     launch_probe_rng(L, ctr, key, (uint32_t*)o.p, (double*)u.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, o.p, 16, hipMemcpyDeviceToHost, c->stream));

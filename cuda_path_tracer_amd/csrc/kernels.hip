@@ -150,9 +150,9 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
 #define CPT_PW_THREADS 1024
 #define CPT_PW_WAVES (CPT_PW_THREADS / CPT_WAVE)
 #define CPT_PW_CACHE_RECORDS 512  // 64 KB of 128-byte records
-#define CPT_PW_STACK_LDS 16
+#define CPT_PW_STACK_LDS 12
 static_assert(CPT_PW_STACK_LDS == CPT_PW_STACK_LDS_HOST, "stack split must match the spill buffer sizing");
-#define CPT_PW_LEAF_CAP 6     // parked leaves per lane (a node expansion adds at most two)
+#define CPT_PW_LEAF_CAP 10    // parked leaves per lane (a node expansion adds at most two)
 
 struct Rec7 {  // the first seven 16-byte pieces of a 128-byte record
     double2 p0, p1, p2, p3, p4, p5, p6;
@@ -185,7 +185,7 @@ __device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, cons
 template <bool COUNT>
 __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStream in, HitBuf hit,
                                                               const uint32_t* __restrict__ counter, uint32_t* cursor,
-                                                              uint32_t chunk, uint32_t refill_at, uint32_t leaf_go, uint32_t* spill, unsigned long long* work) {
+                                                              uint32_t chunk, uint32_t refill_at, uint32_t leaf_go, uint32_t full_go, uint32_t* spill, unsigned long long* work) {
     __shared__ __attribute__((aligned(128))) unsigned char s_cache[CPT_PW_CACHE_RECORDS * 128];
     __shared__ uint32_t s_nodes[CPT_PW_WAVES][CPT_PW_STACK_LDS][CPT_WAVE];
     __shared__ uint32_t s_leaves[CPT_PW_WAVES][CPT_PW_LEAF_CAP][CPT_WAVE];
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     double best_t = -1.0;
     int best_tri = -1;
     uint32_t best_rank = 0xFFFFFFFFu;
-    unsigned long long steps = 0, tris = 0, exact = 0;
+    unsigned long long steps = 0, tris = 0, exact = 0, box_passes = 0, leaf_passes = 0;
 
     for (;;) {
         // ---- refill idle lanes ----
@@ -266,6 +266,10 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
         }
 
         // ---- box phase: expand one node per lane that has one (and room to park two more leaves) ----
+        if (COUNT) {
+            uint64_t boxing = __ballot(node >= 0 && lp <= CPT_PW_LEAF_CAP - 2);
+            if (lane == 0 && boxing) box_passes++;
+        }
         if (node >= 0 && lp <= CPT_PW_LEAF_CAP - 2) {
             Rec7 r = fetch_record(sc.nodes, cache, 0, cached_nodes, node);
             int2 refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));  // lref, rref
@@ -304,7 +308,8 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
         if (have_leaf) {
             uint64_t have_node = __ballot(node >= 0);
             uint64_t nearly_full = __ballot(lp > CPT_PW_LEAF_CAP - 2);
-            if ((uint32_t)__popcll(have_leaf) >= leaf_go || have_node == 0 || nearly_full) {
+            if ((uint32_t)__popcll(have_leaf) >= leaf_go || (have_node & ~nearly_full) == 0 || (uint32_t)__popcll(nearly_full) >= full_go) {
+                if (COUNT && lane == 0) leaf_passes++;
                 if (lp > 0) {
                     --lp;
                     int tri = (int)my_leaves[lp * CPT_WAVE];
@@ -330,6 +335,8 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
         if (steps) atomicAdd(&work[3], steps);
         if (tris) atomicAdd(&work[4], tris);
         if (exact) atomicAdd(&work[5], exact);
+        if (box_passes) atomicAdd(&work[6], box_passes);
+        if (leaf_passes) atomicAdd(&work[7], leaf_passes);
     }
 }
 
@@ -553,8 +560,8 @@ void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, co
 void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
                       uint32_t* cursor, uint32_t* spill, unsigned long long* work) {
     int g = L.pw_blocks;
-    if (work) hipLaunchKernelGGL(k_extend_pw<true>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, cursor, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go, spill, work);
-    else hipLaunchKernelGGL(k_extend_pw<false>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, cursor, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go, spill, work);
+    if (work) hipLaunchKernelGGL(k_extend_pw<true>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, cursor, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go, (uint32_t)L.pw_full_go, spill, work);
+    else hipLaunchKernelGGL(k_extend_pw<false>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, cursor, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go, (uint32_t)L.pw_full_go, spill, work);
 }
 void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& in, const HitBuf& hit,
                   const RayStream& out, const Radiance& col, int batch_s0, int bounce, const uint32_t* counter_in,

@@ -85,7 +85,7 @@ struct Radiance {           // radiance gathered per path, indexed by slot; touc
 #define CPT_SLOT_BYTES (2 * CPT_STREAM_BYTES + 12 + 24)  // device bytes per path slot of a batch
 
 // traversal stack of the persistent-wave extend kernel: entries in LDS, and the deepest tree it accepts
-#define CPT_PW_STACK_LDS_HOST 16
+#define CPT_PW_STACK_LDS_HOST 12
 #define CPT_PW_STACK_MAX 62
 #define CPT_PW_THREADS_HOST 1024
 
@@ -95,6 +95,7 @@ struct LaunchCfg {
     int pw_blocks;   // number of persistent 1024-thread workgroups of k_extend_pw (one per CU)
     int pw_chunk;    // queue entries a wave takes per atomic
     int pw_refill;   // a wave refills when at least this many of its lanes are idle
+    int pw_full_go;  // ... or when at least this many lanes cannot expand a node because their parked-leaf list is full
     int pw_leaf_go;  // a wave runs its triangle phase when at least this many lanes have a parked leaf
 };
 

@@ -122,6 +122,8 @@ typedef struct cpt_stats {
     double ms_generate, ms_extend, ms_shade, ms_mega, ms_total; /* HIP-event time on the render stream */
     uint64_t iterations;
     uint64_t exact_node_steps;  /* node steps whose boxes were re-tested with the reference's divisions */
+    uint64_t box_passes;        /* wave-level passes over the box code of the persistent extend kernel (64 lane slots each) */
+    uint64_t leaf_passes;       /* wave-level passes over its triangle code */
 } cpt_stats;
 
 typedef struct cpt_ctx cpt_ctx;

@@ -62,6 +62,9 @@ def main():
         print("   work: segments %d node_steps %d tri_tests %d exact_node_steps %d (%.3f%%)" %
               (st["segments"], st["node_steps"], st["tri_tests"], st["exact_node_steps"],
                100.0 * st["exact_node_steps"] / max(1, st["node_steps"])), flush=True)
+        print("   lanes: box passes %d (%.1f%% of lane slots used), leaf passes %d (%.1f%%)" %
+              (st["box_passes"], 100.0 * st["node_steps"] / max(1, 64 * st["box_passes"]),
+               st["leaf_passes"], 100.0 * st["tri_tests"] / max(1, 64 * st["leaf_passes"])), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,3 +1,5 @@
-for r in 4 12 24; do for l in 8 20 32 48; do
-  echo "== refill $r leaf_go $l"; timeout -k 5 100 python tools/prof_render.py --spp 64 --depth 8 --repeat 2 --stats --opt pw_refill=$r --opt pw_leaf_go=$l | tail -1 || exit 1
-done; done
+timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread 2>&1 | tail -3 || exit 1
+for l in 32 44 56; do
+  echo "== leaf_go $l"; timeout -k 5 100 python tools/prof_render.py --spp 64 --depth 8 --repeat 2 --stats --count --opt pw_leaf_go=$l | tail -3 || exit 1
+  timeout -k 5 100 python tools/prof_render.py --scene dragon-spec --width 1024 --spp 16 --depth 8 --repeat 2 --stats --count --opt pw_leaf_go=$l | tail -3 || exit 1
+done
