@@ -176,11 +176,12 @@ def main():
         counted = [r.stats() for (r, *_rest) in renderers]
         for (r, *_rest) in renderers:
             r.set_instrumentation(False, False)
-        agg = {k: sum(c[k] for c in counted) for k in ("paths", "segments", "hits", "node_steps", "tri_tests")}
+        agg = {k: sum(c[k] for c in counted) for k in ("paths", "segments", "hits", "node_steps", "tri_tests",
+                                                        "exact_node_steps", "box_passes", "leaf_passes")}
         if mode == MODE_WAVEFRONT:
             ms = sum(t["ms_extend"] for t in timed)
             launches = sum(t["launches_extend"] for t in timed)
-            kernel, kbytes = "k_extend", extend_bytes(agg)
+            kernel, kbytes = "k_extend_pw", extend_bytes(agg)
         else:
             ms = sum(t["ms_mega"] for t in timed)
             launches = sum(t["launches_mega"] for t in timed)
@@ -197,6 +198,12 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "bytes_per_launch": kbytes / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
                 "launches_per_step": launches,
+                "note": "algorithmic bytes count every node and triangle record a ray touches; the kernel serves them "
+                        "from a per-CU LDS copy (and L2), so the rate can exceed the HBM peak and `traffic` (measured HBM "
+                        "bytes per launch) is far below bytes_per_launch; the kernel's physical bound is fp64 VALU issue",
+                "lane_slots_used": {"box": agg["node_steps"] / max(64 * agg["box_passes"], 1),
+                                    "triangle": agg["tri_tests"] / max(64 * agg["leaf_passes"], 1)},
+                "exact_box_fallbacks": agg["exact_node_steps"],
                 "pipeline_GBps": pipeline_bytes(agg) / (sum(t["ms_total"] for t in timed) * 1e-3) / 1e9,
                 "per_segment": {"node_steps": agg["node_steps"] / max(agg["segments"], 1),
                                 "tri_tests": agg["tri_tests"] / max(agg["segments"], 1),
