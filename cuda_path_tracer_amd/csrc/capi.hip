@@ -337,6 +337,8 @@ static int collect_work(cpt_ctx* c) {
     return CPT_OK;
 }
 
+static int ensure_spill(cpt_ctx* c);
+
 int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
     if (!c || !p || !d_accum) return c ? fail(c, CPT_EINVAL, "cpt_render: NULL argument") : CPT_EINVAL;
     if (!c->has_scene) return fail(c, CPT_ENOSCENE, "cpt_render: no scene uploaded");
@@ -369,13 +371,8 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
     }
 
     // wavefront: batches of whole samples
-    if (c->extend_variant == 1 && c->spill_blocks < c->pw_blocks) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->d_spill) (void)hipFree(c->d_spill);
-        c->d_spill = nullptr;
-        HIP_TRY(c, hipMalloc((void**)&c->d_spill, (size_t)(CPT_PW_STACK_MAX - CPT_PW_STACK_LDS_HOST) * (size_t)c->pw_blocks * CPT_PW_THREADS_HOST * sizeof(uint32_t)));
-        c->spill_blocks = c->pw_blocks;
-    }
+    rc = ensure_spill(c);
+    if (rc) return rc;
     long long per_sample = P.n_pix_slots;
     int batch = (int)std::max(1ll, std::min((long long)(P.s1 - P.s0), c->batch_paths / per_sample));
     rc = ensure_paths(c, (size_t)batch * (size_t)per_sample);
@@ -515,6 +512,48 @@ int cpt_trace_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, 
     if (h_counts) HIP_TRY(c, hipMemcpyAsync(h_counts, cnt.p, N * 16, hipMemcpyDeviceToHost, c->stream));
     if (h_bitmap) HIP_TRY(c, hipMemcpyAsync(h_bitmap, bm.p, N * (size_t)stride, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CPT_OK;
+}
+
+static int ensure_spill(cpt_ctx* c) {
+    if (c->extend_variant != 1 || c->spill_blocks >= c->pw_blocks) return CPT_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_spill) (void)hipFree(c->d_spill);
+    c->d_spill = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&c->d_spill, (size_t)(CPT_PW_STACK_MAX - CPT_PW_STACK_LDS_HOST) * (size_t)c->pw_blocks * CPT_PW_THREADS_HOST * sizeof(uint32_t)));
+    c->spill_blocks = c->pw_blocks;
+    return CPT_OK;
+}
+
+int cpt_extend_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, int32_t* h_tri, double* h_t) {
+    if (!c || !h_o || !h_d || !h_tri || !h_t || n < 0) return c ? fail(c, CPT_EINVAL, "cpt_extend_rays: bad argument") : CPT_EINVAL;
+    if (!c->has_scene) return fail(c, CPT_ENOSCENE, "cpt_extend_rays: no scene uploaded");
+    if (n == 0) return CPT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_spill(c);
+    if (rc) return rc;
+    rc = ensure_paths(c, (size_t)n);
+    if (rc) return rc;
+    const size_t N = (size_t)n;
+    std::vector<double> soa(6 * N);  // the stream is structure-of-arrays by position
+    for (size_t i = 0; i < N; ++i)
+        for (int k = 0; k < 3; ++k) { soa[(size_t)k * N + i] = h_o[3 * i + k]; soa[(size_t)(3 + k) * N + i] = h_d[3 * i + k]; }
+    const RayStream& in = c->R[0];
+    double* dst[6] = {in.ox, in.oy, in.oz, in.dx, in.dy, in.dz};
+    for (int k = 0; k < 6; ++k) HIP_TRY(c, hipMemcpyAsync(dst[k], soa.data() + (size_t)k * N, N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    uint32_t* cursors = c->d_counters + (CPT_MAX_DEPTH + 2);
+    HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_counters, n, 1, c->stream));
+    HIP_TRY(c, hipMemsetAsync(cursors, 0, sizeof(uint32_t), c->stream));
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
+    unsigned long long* work = c->count_work ? c->d_work : nullptr;
+    if (c->extend_variant == 1) launch_extend_pw(L, c->sc, in, c->H, c->d_counters, cursors, c->d_spill, work);
+    else launch_extend(L, c->sc, in, c->H, c->d_counters, (long long)n, work);
+    HIP_TRY(c, hipGetLastError());
+    c->stats.launches_extend++;
+    HIP_TRY(c, hipMemcpyAsync(h_t, c->H.t, N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_tri, c->H.tri, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (work) return collect_work(c);
     return CPT_OK;
 }
 

@@ -98,6 +98,17 @@ class Renderer:
         self._check(self._L.cpt_reset_stats(self._h), "cpt_reset_stats")
 
     # --- parity hooks ---------------------------------------------------------------------------
+    def extend_rays(self, origins, dirs):
+        """Closest hits of explicit rays through the pipeline's own extend kernel: (tri, t)."""
+        o = np.ascontiguousarray(origins, np.float64)
+        d = np.ascontiguousarray(dirs, np.float64)
+        n = o.shape[0]
+        tri = np.empty(n, np.int32)
+        t = np.empty(n, np.float64)
+        self._check(self._L.cpt_extend_rays(self._h, n, o.ctypes.data, d.ctypes.data, tri.ctypes.data, t.ctypes.data),
+                    "cpt_extend_rays")
+        return tri, t
+
     def trace_rays(self, origins, dirs, bitmap=False):
         o = np.ascontiguousarray(origins, np.float64)
         d = np.ascontiguousarray(dirs, np.float64)

@@ -175,6 +175,15 @@ int cpt_reset_stats(cpt_ctx* ctx);
 
 /* ---- parity hooks ----------------------------------------------------------------------- */
 
+/* Closest hits of n explicit rays through the wavefront pipeline's own extend kernel (the variant
+ * selected by the "extend_variant" option), i.e. the kernel cpt_render launches once per bounce, fed
+ * with the caller's rays instead of a generated stream.  Host arrays: h_origin/h_dir n*3 doubles in,
+ * h_tri n (triangle index or -1) and h_t n out.  With work counting on, cpt_get_stats afterwards
+ * reports the node steps, triangle tests and exact-box fallbacks of the call.
+ * Observes the extend half of pathTrace (reference: src/improved_path_tracer.cu:60-75), which calls
+ * GPU::BVH::traverseIterative (src/gpu/GPUBVH.cu:38-99). */
+int cpt_extend_rays(cpt_ctx* ctx, int32_t n, const double* h_origin, const double* h_dir, int32_t* h_tri, double* h_t);
+
 /* Intersect n explicit rays with the scene using exactly the render path's traversal.
  * Host arrays: h_origin/h_dir n*3 doubles.  Outputs (host): h_tri n (triangle index or -1),
  * h_t n, h_normal n*3 (shading normal of the hit, nullable), h_visit_hash n (sum over tested
