@@ -51,7 +51,7 @@ struct cpt_ctx {
     int pw_blocks = 0;             // persistent workgroups of the extend kernel (one per CU)
     int pw_chunk = 256;            // queue entries a persistent wave takes per atomic
     int pw_refill = 12, pw_leaf_go = 32, pw_full_go = 1;
-    int extend_variant = 1;        // 0: one ray per thread; 1: persistent waves with refill
+    int extend_variant = 1;        // 0: one ray per thread; 1: persistent waves with refill; 2: as 1, nearest-first with culling
 };
 
 static thread_local std::string g_create_error;
@@ -165,7 +165,7 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
         if (value < 1 || value > 64) return fail(c, CPT_EINVAL, "pw_leaf_go must be in [1, 64]");
         c->pw_leaf_go = (int)value;
     } else if (!strcmp(key, "extend_variant")) {
-        if (value != 0 && value != 1) return fail(c, CPT_EINVAL, "extend_variant must be 0 or 1");
+        if (value < 0 || value > 2) return fail(c, CPT_EINVAL, "extend_variant must be 0, 1 or 2");
         c->extend_variant = (int)value;
     } else {
         return fail(c, CPT_EINVAL, "unknown option '%s'", key);
@@ -347,7 +347,7 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
     if (rc != CPT_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     if (P.s1 == P.s0) return CPT_OK;
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     unsigned long long* work = c->count_work ? c->d_work : nullptr;
     const bool timed = c->time_kernels;
     long long n_paths = (long long)P.w * P.h * (P.s1 - P.s0);
@@ -392,7 +392,7 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
         if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
         for (int b = 0; b <= P.depth; ++b) {
             const RayStream& in = c->R[b & 1];
-            if (c->extend_variant == 1) launch_extend_pw(L, c->sc, in, c->H, c->d_counters + b, cursors + b, c->d_spill, work);
+            if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, c->H, c->d_counters + b, cursors + b, c->d_spill, work);
             else launch_extend(L, c->sc, in, c->H, c->d_counters + b, slots, work);
             if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
             launch_shade(L, c->sc, P, in, c->H, c->R[(b + 1) & 1], c->C, bs, b, c->d_counters + b, c->d_counters + b + 1, slots, work);
@@ -429,7 +429,7 @@ int cpt_tonemap(cpt_ctx* c, const double* d_accum, int32_t w, int32_t h, int32_t
     if (!c || !d_accum || !d_rgb) return c ? fail(c, CPT_EINVAL, "cpt_tonemap: NULL argument") : CPT_EINVAL;
     if (w < 1 || h < 1 || total_spp < 1) return fail(c, CPT_EINVAL, "cpt_tonemap: bad size or sample count");
     HIP_TRY(c, hipSetDevice(c->device));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     launch_tonemap(L, d_accum, w * h * 3, total_spp, d_rgb);
     HIP_TRY(c, hipGetLastError());
     return CPT_OK;
@@ -501,7 +501,7 @@ int cpt_trace_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, 
     if (h_bitmap) { HIP_TRY(c, bm.alloc(N * (size_t)stride)); HIP_TRY(c, hipMemsetAsync(bm.p, 0, N * (size_t)stride, c->stream)); }
     HIP_TRY(c, hipMemcpyAsync(o.p, h_o, N * 24, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d.p, h_d, N * 24, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     launch_trace_rays(L, c->sc, n, (const double*)o.p, (const double*)d.p, (int*)tri.p, (double*)t.p, (double*)nrm.p,
                       (unsigned long long*)vh.p, (int*)cnt.p, h_bitmap ? (uint8_t*)bm.p : nullptr, stride);
     HIP_TRY(c, hipGetLastError());
@@ -516,7 +516,7 @@ int cpt_trace_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, 
 }
 
 static int ensure_spill(cpt_ctx* c) {
-    if (c->extend_variant != 1 || c->spill_blocks >= c->pw_blocks) return CPT_OK;
+    if (c->extend_variant < 1 || c->spill_blocks >= c->pw_blocks) return CPT_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->d_spill) (void)hipFree(c->d_spill);
     c->d_spill = nullptr;
@@ -544,9 +544,9 @@ int cpt_extend_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d,
     uint32_t* cursors = c->d_counters + (CPT_MAX_DEPTH + 2);
     HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_counters, n, 1, c->stream));
     HIP_TRY(c, hipMemsetAsync(cursors, 0, sizeof(uint32_t), c->stream));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     unsigned long long* work = c->count_work ? c->d_work : nullptr;
-    if (c->extend_variant == 1) launch_extend_pw(L, c->sc, in, c->H, c->d_counters, cursors, c->d_spill, work);
+    if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, c->H, c->d_counters, cursors, c->d_spill, work);
     else launch_extend(L, c->sc, in, c->H, c->d_counters, (long long)n, work);
     HIP_TRY(c, hipGetLastError());
     c->stats.launches_extend++;
@@ -564,7 +564,7 @@ int cpt_camera_rays(cpt_ctx* c, int32_t w, int32_t h, double jx, double jy, doub
     size_t N = (size_t)w * h;
     DevBuf o, d;
     HIP_TRY(c, o.alloc(N * 24)); HIP_TRY(c, d.alloc(N * 24));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     launch_camera_rays(L, c->sc, w, h, jx, jy, (double*)o.p, (double*)d.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_o, o.p, N * 24, hipMemcpyDeviceToHost, c->stream));
@@ -588,7 +588,7 @@ int cpt_path_radiance(cpt_ctx* c, const cpt_render_params* p, int32_t n, const i
     size_t N = (size_t)n;
     HIP_TRY(c, ij.alloc(N * 12)); HIP_TRY(c, rad.alloc(N * 24));
     HIP_TRY(c, hipMemcpyAsync(ij.p, h_ijs, N * 12, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     launch_path_radiance(L, c->sc, P, n, (const int*)ij.p, (double*)rad.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_rad, rad.p, N * 24, hipMemcpyDeviceToHost, c->stream));
@@ -605,7 +605,7 @@ int cpt_probe_math(cpt_ctx* c, int32_t n, const double* h_a, const double* h_b, 
     HIP_TRY(c, a.alloc(N * 8)); HIP_TRY(c, b.alloc(N * 8)); HIP_TRY(c, s.alloc(N * 8)); HIP_TRY(c, q.alloc(N * 8));
     HIP_TRY(c, hipMemcpyAsync(a.p, h_a, N * 8, hipMemcpyHostToDevice, c->stream));
     if (h_b) HIP_TRY(c, hipMemcpyAsync(b.p, h_b, N * 8, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     launch_probe_math(L, n, (const double*)a.p, h_b ? (const double*)b.p : nullptr, (double*)s.p, (double*)q.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_sqrt, s.p, N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -619,7 +619,7 @@ int cpt_probe_rng(cpt_ctx* c, const uint32_t ctr[4], const uint32_t key[2], uint
     HIP_TRY(c, hipSetDevice(c->device));
     DevBuf o, u;
     HIP_TRY(c, o.alloc(16)); HIP_TRY(c, u.alloc(16));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     launch_probe_rng(L, ctr, key, (uint32_t*)o.p, (double*)u.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, o.p, 16, hipMemcpyDeviceToHost, c->stream));

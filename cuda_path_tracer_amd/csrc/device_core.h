@@ -36,7 +36,7 @@ __device__ __forceinline__ uint64_t visit_mix(uint32_t id) {
 // the axis loop; a failed axis can never be undone by a later one, so the axes are evaluated
 // without branches and the verdicts are combined.
 __device__ __forceinline__ bool slab_hit(double lx, double ly, double lz, double hx, double hy, double hz,
-                                         const dvec3& o, const dvec3& d) {
+                                         const dvec3& o, const dvec3& d, double& t_enter) {
     double tMin = -1.0e308, tMax = 1.0e308;
     bool ok = true;
 #define CPT_SLAB_AXIS(LO, HI, O, D)                         \
@@ -57,7 +57,13 @@ __device__ __forceinline__ bool slab_hit(double lx, double ly, double lz, double
     CPT_SLAB_AXIS(ly, hy, o.y, d.y)
     CPT_SLAB_AXIS(lz, hz, o.z, d.z)
 #undef CPT_SLAB_AXIS
+    t_enter = tMin;
     return ok;
+}
+__device__ __forceinline__ bool slab_hit(double lx, double ly, double lz, double hx, double hy, double hz,
+                                         const dvec3& o, const dvec3& d) {
+    double unused;
+    return slab_hit(lx, ly, lz, hx, hy, hz, o, d, unused);
 }
 
 // The same verdict as slab_hit, usually without dividing.  With r = 1/d rounded once per ray,
@@ -95,7 +101,7 @@ __device__ __forceinline__ SlabRay slab_prepare(const dvec3& o, const dvec3& d) 
     return s;
 }
 __device__ __forceinline__ bool slab_filtered(double lx, double ly, double lz, double hx, double hy, double hz,
-                                              const dvec3& o, const SlabRay& s, bool& sure) {
+                                              const dvec3& o, const SlabRay& s, bool& sure, double& t_enter) {
     double x1 = (lx - o.x) * s.r.x, x2 = (hx - o.x) * s.r.x;
     double y1 = (ly - o.y) * s.r.y, y2 = (hy - o.y) * s.r.y;
     double z1 = (lz - o.z) * s.r.z, z2 = (hz - o.z) * s.r.z;
@@ -108,7 +114,13 @@ __device__ __forceinline__ bool slab_filtered(double lx, double ly, double lz, d
     double m = fma(fabs(tf) + fabs(tn), 2e-15, 1e-300);
     bool hit = (g > m) && (tf > 1.000000000000001e-12);
     sure = hit || (g < -m) || (tf < 0.999999999999999e-12);
+    t_enter = tn;
     return hit;
+}
+__device__ __forceinline__ bool slab_filtered(double lx, double ly, double lz, double hx, double hy, double hz,
+                                              const dvec3& o, const SlabRay& s, bool& sure) {
+    double unused;
+    return slab_filtered(lx, ly, lz, hx, hy, hz, o, s, sure, unused);
 }
 
 // Ray/triangle test (reference: src/gpu/GPUTrimesh.cuh:59-113): plane hit, back-face cull unless

@@ -182,7 +182,12 @@ __device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, cons
     return r;
 }
 
-template <bool COUNT>
+//
+// CULL selects the fast mode: of two child boxes that are both hit the nearer one is walked first, and
+// a box the ray enters beyond the closest hit found so far (with a relative margin of 1e-6) is not
+// walked at all.  The closest hit is the same one; the set of visited nodes, which the reference
+// mode reproduces exactly, is not.
+template <bool COUNT, bool CULL>
 __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStream in, HitBuf hit,
                                                               const uint32_t* __restrict__ counter, uint32_t* cursor,
                                                               uint32_t chunk, uint32_t refill_at, uint32_t leaf_go, uint32_t full_go, uint32_t* spill, unsigned long long* work) {
@@ -274,12 +279,23 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
             Rec7 r = fetch_record(sc.nodes, cache, 0, cached_nodes, node);
             int2 refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));  // lref, rref
             bool sure_l, sure_r;
-            bool hl = slab_filtered(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, sr, sure_l);
-            bool hr = slab_filtered(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, sr, sure_r);
+            double enter_l, enter_r;
+            bool hl = slab_filtered(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, sr, sure_l, enter_l);
+            bool hr = slab_filtered(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, sr, sure_r, enter_r);
             if (sr.exact_only || !(sure_l && sure_r)) {
                 if (COUNT) exact++;
-                hl = slab_hit(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, d);
-                hr = slab_hit(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, d);
+                hl = slab_hit(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, d, enter_l);
+                hr = slab_hit(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, d, enter_r);
+            }
+            if (CULL) {
+                if (best_t >= 0) {
+                    const double limit = best_t * 1.000001 + 1e-9;
+                    hl = hl && !(enter_l > limit);
+                    hr = hr && !(enter_r > limit);
+                }
+                if (hl && hr && refs.x >= 0 && refs.y >= 0 && enter_r < enter_l) {  // nearer child first
+                    int tmp = refs.x; refs.x = refs.y; refs.y = tmp;
+                }
             }
             if (COUNT) steps++;
             if (hl && refs.x < 0) { my_leaves[lp * CPT_WAVE] = (uint32_t)(~refs.x); ++lp; }
@@ -560,8 +576,18 @@ void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, co
 void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
                       uint32_t* cursor, uint32_t* spill, unsigned long long* work) {
     int g = L.pw_blocks;
-    if (work) hipLaunchKernelGGL(k_extend_pw<true>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, cursor, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go, (uint32_t)L.pw_full_go, spill, work);
-    else hipLaunchKernelGGL(k_extend_pw<false>, dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, cursor, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go, (uint32_t)L.pw_full_go, spill, work);
+#define CPT_PW_LAUNCH(COUNT, CULL)                                                                                  \
+    hipLaunchKernelGGL((k_extend_pw<COUNT, CULL>), dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, \
+                       cursor, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go,                  \
+                       (uint32_t)L.pw_full_go, spill, work)
+    if (L.pw_cull) {
+        if (work) CPT_PW_LAUNCH(true, true);
+        else CPT_PW_LAUNCH(false, true);
+    } else {
+        if (work) CPT_PW_LAUNCH(true, false);
+        else CPT_PW_LAUNCH(false, false);
+    }
+#undef CPT_PW_LAUNCH
 }
 void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& in, const HitBuf& hit,
                   const RayStream& out, const Radiance& col, int batch_s0, int bounce, const uint32_t* counter_in,

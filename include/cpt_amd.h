@@ -139,8 +139,13 @@ const char* cpt_last_error(const cpt_ctx* ctx);
 int cpt_set_stream(cpt_ctx* ctx, void* hip_stream);
 /* Tuning knobs, by name: "batch_paths" (path slots the wavefront pipeline keeps in flight,
  * default 2^23), "max_blocks" (grid cap of the grid-stride kernels, default 8 per CU),
- * "extend_variant" (1: persistent waves with an LDS record cache, default; 0: one ray per thread),
- * "pw_blocks" / "pw_chunk" (workgroups of the persistent extend kernel / rays claimed per atomic). */
+ * "extend_variant" (1: persistent waves with an LDS record cache, default; 0: one ray per thread;
+ * 2: as 1 but walking the nearer child first and skipping boxes entered beyond the closest hit so
+ * far -- a fast mode that returns the same hits without reproducing the reference's visit set),
+ * "pw_blocks" / "pw_chunk" (workgroups of the persistent extend kernel / rays claimed per atomic),
+ * "pw_refill" / "pw_leaf_go" / "pw_full_go" (a wave of that kernel refills when this many lanes are
+ * idle / runs its triangle pass when this many lanes have a parked leaf / or when this many lanes
+ * cannot go on because their parked-leaf list is full). */
 int cpt_set_option(cpt_ctx* ctx, const char* key, long long value);
 /* Turn per-launch HIP-event timing and device-side work counters on or off (both default off). */
 int cpt_set_instrumentation(cpt_ctx* ctx, int time_kernels, int count_work);
