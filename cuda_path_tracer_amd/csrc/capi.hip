@@ -16,6 +16,7 @@
 
 #define CPT_STACK_ENTRIES_HOST 32  // must equal CPT_STACK_ENTRIES in device_core.h
 #define CPT_MAX_DEPTH 1022
+#define CPT_MAX_LANES 4
 
 static_assert(sizeof(cpt_node) == 128, "cpt_node must be 128 bytes");
 static_assert(sizeof(cpt_tri) == 128, "cpt_tri must be 128 bytes");
@@ -32,15 +33,25 @@ struct cpt_ctx {
     bool has_scene = false;
     int n_tree_nodes = 0, tree_height = 0;
 
-    void* d_paths = nullptr;               // one allocation: two ray streams, hit buffer, per-slot radiance
-    size_t path_capacity = 0;              // in path slots
-    RayStream R[2]{};
-    HitBuf H{};
-    Radiance C{};
-    uint32_t* d_counters = nullptr;        // CPT_MAX_DEPTH + 2 stream lengths, then as many claim cursors
+    // A lane is everything one batch of paths needs while it is in flight.  Consecutive batches of a
+    // render go to alternating lanes, each on its own HIP stream, so that the arithmetic-bound extend
+    // kernel of one batch runs under the memory-bound shade kernel of the other.
+    struct Lane {
+        hipStream_t own_stream = nullptr;  // lane 0 runs on the context's stream instead
+        void* d_paths = nullptr;           // one allocation: two ray streams, hit buffer, per-slot radiance
+        size_t path_capacity = 0;          // in path slots
+        RayStream R[2]{};
+        HitBuf H{};
+        Radiance C{};
+        uint32_t* d_counters = nullptr;    // CPT_MAX_DEPTH + 2 stream lengths, then as many claim cursors
+        uint32_t* d_spill = nullptr;       // stack overflow columns of the persistent-wave extend kernel
+        int spill_blocks = 0;
+        hipEvent_t resolved = nullptr;     // recorded after the lane's latest k_resolve
+    };
+    Lane lanes[CPT_MAX_LANES];
+    int n_lanes = 2;
+    hipEvent_t ev_fork = nullptr;
     unsigned long long* d_work = nullptr;  // paths, segments, hits, node steps, triangle tests
-    uint32_t* d_spill = nullptr;           // stack overflow columns of the persistent-wave extend kernel
-    int spill_blocks = 0;
 
     bool time_kernels = false, count_work = false;
     cpt_stats stats{};
@@ -79,11 +90,12 @@ static void free_scene(cpt_ctx* c) {
     c->d_nodes = c->d_tris = c->d_shade = nullptr;
     c->has_scene = false;
 }
-static void free_paths(cpt_ctx* c) {
-    if (c->d_paths) (void)hipFree(c->d_paths);
-    c->d_paths = nullptr;
-    c->path_capacity = 0;
+static void free_paths(cpt_ctx::Lane& l) {
+    if (l.d_paths) (void)hipFree(l.d_paths);
+    l.d_paths = nullptr;
+    l.path_capacity = 0;
 }
+static hipStream_t lane_stream(cpt_ctx* c, int k) { return k == 0 ? c->stream : c->lanes[k].own_stream; }
 
 extern "C" {
 
@@ -104,7 +116,12 @@ int cpt_create(int device, cpt_ctx** out) {
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(nullptr, CPT_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
-    e = hipMalloc((void**)&c->d_counters, 2 * (CPT_MAX_DEPTH + 2) * sizeof(uint32_t));
+    for (int k = 0; k < CPT_MAX_LANES && e == hipSuccess; ++k) {
+        e = hipMalloc((void**)&c->lanes[k].d_counters, 2 * (CPT_MAX_DEPTH + 2) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->lanes[k].resolved, hipEventDisableTiming);
+        if (e == hipSuccess && k > 0) e = hipStreamCreateWithFlags(&c->lanes[k].own_stream, hipStreamNonBlocking);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_work, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->d_work, 0, 8 * sizeof(unsigned long long));
     if (e != hipSuccess) { cpt_destroy(c); return fail(nullptr, CPT_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
@@ -116,11 +133,18 @@ void cpt_destroy(cpt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (int k = 0; k < CPT_MAX_LANES; ++k) {
+        cpt_ctx::Lane& l = c->lanes[k];
+        if (l.own_stream) (void)hipStreamSynchronize(l.own_stream);
+        free_paths(l);
+        if (l.d_counters) (void)hipFree(l.d_counters);
+        if (l.d_spill) (void)hipFree(l.d_spill);
+        if (l.resolved) (void)hipEventDestroy(l.resolved);
+        if (l.own_stream) (void)hipStreamDestroy(l.own_stream);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     free_scene(c);
-    free_paths(c);
-    if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_work) (void)hipFree(c->d_work);
-    if (c->d_spill) (void)hipFree(c->d_spill);
     for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -146,6 +170,9 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
     if (!strcmp(key, "batch_paths")) {
         if (value < 64) return fail(c, CPT_EINVAL, "batch_paths must be >= 64");
         c->batch_paths = value;
+    } else if (!strcmp(key, "streams")) {
+        if (value < 1 || value > CPT_MAX_LANES) return fail(c, CPT_EINVAL, "streams must be in [1, %d]", CPT_MAX_LANES);
+        c->n_lanes = (int)value;
     } else if (!strcmp(key, "max_blocks")) {
         if (value < 1) return fail(c, CPT_EINVAL, "max_blocks must be >= 1");
         c->max_blocks = (int)value;
@@ -274,27 +301,37 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     return CPT_OK;
 }
 
-static int ensure_paths(cpt_ctx* c, size_t slots) {
-    if (slots <= c->path_capacity) return CPT_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    free_paths(c);
+static int ensure_paths(cpt_ctx* c, cpt_ctx::Lane& l, hipStream_t st, size_t slots) {
+    if (slots <= l.path_capacity) return CPT_OK;
+    HIP_TRY(c, hipStreamSynchronize(st));
+    free_paths(l);
     slots = (slots + 63) / 64 * 64;  // keeps every array 512-byte aligned
-    HIP_TRY(c, hipMalloc(&c->d_paths, slots * CPT_SLOT_BYTES));
-    double* p = (double*)c->d_paths;
+    HIP_TRY(c, hipMalloc(&l.d_paths, slots * CPT_SLOT_BYTES));
+    double* p = (double*)l.d_paths;
     for (int b = 0; b < 2; ++b) {
-        double** f[CPT_STREAM_DOUBLES] = {&c->R[b].ox, &c->R[b].oy, &c->R[b].oz, &c->R[b].dx, &c->R[b].dy, &c->R[b].dz,
-                                          &c->R[b].medium, &c->R[b].ax, &c->R[b].ay, &c->R[b].az};
+        double** f[CPT_STREAM_DOUBLES] = {&l.R[b].ox, &l.R[b].oy, &l.R[b].oz, &l.R[b].dx, &l.R[b].dy, &l.R[b].dz,
+                                          &l.R[b].medium, &l.R[b].ax, &l.R[b].ay, &l.R[b].az};
         for (int k = 0; k < CPT_STREAM_DOUBLES; ++k) { *f[k] = p; p += slots; }
     }
-    c->H.t = p; p += slots;
-    c->C.cx = p; p += slots;
-    c->C.cy = p; p += slots;
-    c->C.cz = p; p += slots;
+    l.H.t = p; p += slots;
+    l.C.cx = p; p += slots;
+    l.C.cy = p; p += slots;
+    l.C.cz = p; p += slots;
     uint32_t* u = (uint32_t*)p;
-    c->R[0].slot = u; u += slots;
-    c->R[1].slot = u; u += slots;
-    c->H.tri = (int*)u;
-    c->path_capacity = slots;
+    l.R[0].slot = u; u += slots;
+    l.R[1].slot = u; u += slots;
+    l.H.tri = (int*)u;
+    l.path_capacity = slots;
+    return CPT_OK;
+}
+
+static int ensure_spill(cpt_ctx* c, cpt_ctx::Lane& l, hipStream_t st) {
+    if (c->extend_variant < 1 || l.spill_blocks >= c->pw_blocks) return CPT_OK;
+    HIP_TRY(c, hipStreamSynchronize(st));
+    if (l.d_spill) (void)hipFree(l.d_spill);
+    l.d_spill = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&l.d_spill, (size_t)(CPT_PW_STACK_MAX - CPT_PW_STACK_LDS_HOST) * (size_t)c->pw_blocks * CPT_PW_THREADS_HOST * sizeof(uint32_t)));
+    l.spill_blocks = c->pw_blocks;
     return CPT_OK;
 }
 
@@ -337,8 +374,6 @@ static int collect_work(cpt_ctx* c) {
     return CPT_OK;
 }
 
-static int ensure_spill(cpt_ctx* c);
-
 int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
     if (!c || !p || !d_accum) return c ? fail(c, CPT_EINVAL, "cpt_render: NULL argument") : CPT_EINVAL;
     if (!c->has_scene) return fail(c, CPT_ENOSCENE, "cpt_render: no scene uploaded");
@@ -370,42 +405,64 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
         return CPT_OK;
     }
 
-    // wavefront: batches of whole samples
-    rc = ensure_spill(c);
-    if (rc) return rc;
-    long long per_sample = P.n_pix_slots;
-    int batch = (int)std::max(1ll, std::min((long long)(P.s1 - P.s0), c->batch_paths / per_sample));
-    rc = ensure_paths(c, (size_t)batch * (size_t)per_sample);
-    if (rc) return rc;
+    // wavefront: batches of whole samples, dealt to the lanes in turn
+    const long long per_sample = P.n_pix_slots;
+    const int total = P.s1 - P.s0;
+    int batch = (int)std::max(1ll, std::min((long long)total, c->batch_paths / per_sample));
+    int n_lanes = timed ? 1 : c->n_lanes;  // per-kernel times are only meaningful when nothing else runs beside the kernel
+    if (n_lanes > 1) {  // a render that fits one batch is split so that there is something to overlap, unless it is tiny
+        const int share = (total + n_lanes - 1) / n_lanes;
+        if ((long long)share * per_sample >= (1ll << 20)) batch = std::min(batch, share);
+    }
+    const int n_batches = (total + batch - 1) / batch;
+    n_lanes = std::min(n_lanes, n_batches);
+    for (int k = 0; k < n_lanes; ++k) {
+        rc = ensure_spill(c, c->lanes[k], lane_stream(c, k));
+        if (rc) return rc;
+        rc = ensure_paths(c, c->lanes[k], lane_stream(c, k), (size_t)batch * (size_t)per_sample);
+        if (rc) return rc;
+    }
     const size_t n_ev = 2 * (size_t)(P.depth + 1) + 3;
     if (timed) { rc = need_events(c, n_ev); if (rc) return rc; }
-    for (int bs = P.s0; bs < P.s1; bs += batch) {
+    if (n_lanes > 1) {  // the other lanes start after whatever the caller queued before this render
+        HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+        for (int k = 1; k < n_lanes; ++k) HIP_TRY(c, hipStreamWaitEvent(c->lanes[k].own_stream, c->ev_fork, 0));
+    }
+    int last_lane = 0;
+    for (int i = 0, bs = P.s0; bs < P.s1; bs += batch, ++i) {
+        const int k = i % n_lanes;
+        cpt_ctx::Lane& ln = c->lanes[k];
+        L.stream = lane_stream(c, k);
         int bn = std::min(batch, P.s1 - bs);
         long long slots = (long long)bn * per_sample;
         size_t ev = 0;
-        uint32_t* cursors = c->d_counters + (CPT_MAX_DEPTH + 2);
-        HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, (size_t)(P.depth + 2) * sizeof(uint32_t), c->stream));
-        HIP_TRY(c, hipMemsetAsync(cursors, 0, (size_t)(P.depth + 2) * sizeof(uint32_t), c->stream));
-        if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
-        HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_counters, (int)slots, 1, c->stream));
-        launch_generate(L, c->sc, P, c->R[0], c->C, bs, bn);
-        if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
+        uint32_t* cursors = ln.d_counters + (CPT_MAX_DEPTH + 2);
+        HIP_TRY(c, hipMemsetAsync(ln.d_counters, 0, (size_t)(P.depth + 2) * sizeof(uint32_t), L.stream));
+        HIP_TRY(c, hipMemsetAsync(cursors, 0, (size_t)(P.depth + 2) * sizeof(uint32_t), L.stream));
+        if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
+        HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)ln.d_counters, (int)slots, 1, L.stream));
+        launch_generate(L, c->sc, P, ln.R[0], ln.C, bs, bn);
+        if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
         for (int b = 0; b <= P.depth; ++b) {
-            const RayStream& in = c->R[b & 1];
-            if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, c->H, c->d_counters + b, cursors + b, c->d_spill, work);
-            else launch_extend(L, c->sc, in, c->H, c->d_counters + b, slots, work);
-            if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
-            launch_shade(L, c->sc, P, in, c->H, c->R[(b + 1) & 1], c->C, bs, b, c->d_counters + b, c->d_counters + b + 1, slots, work);
-            if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
+            const RayStream& in = ln.R[b & 1];
+            if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, ln.d_counters + b, cursors + b, ln.d_spill, work);
+            else launch_extend(L, c->sc, in, ln.H, ln.d_counters + b, slots, work);
+            if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
+            launch_shade(L, c->sc, P, in, ln.H, ln.R[(b + 1) & 1], ln.C, bs, b, ln.d_counters + b, ln.d_counters + b + 1, slots, work);
+            if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
         }
-        launch_resolve(L, P, c->C, bn, d_accum);
+        // a pixel's samples are added in sample order: this batch's resolve follows the previous batch's
+        if (i > 0 && n_lanes > 1) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->lanes[last_lane].resolved, 0));
+        launch_resolve(L, P, ln.C, bn, d_accum);
         HIP_TRY(c, hipGetLastError());
+        if (n_lanes > 1) HIP_TRY(c, hipEventRecord(ln.resolved, L.stream));
+        last_lane = k;
         c->stats.launches_generate++;
         c->stats.launches_extend += (uint64_t)(P.depth + 1);
         c->stats.launches_shade += (uint64_t)(P.depth + 1);
         c->stats.iterations += (uint64_t)(P.depth + 1);
         if (timed) {
-            HIP_TRY(c, hipEventRecord(c->events[ev++], c->stream));
+            HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
             HIP_TRY(c, hipEventSynchronize(c->events[ev - 1]));
             float ms = 0;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->events[0], c->events[1]));
@@ -420,6 +477,8 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
             c->stats.ms_total += ms;
         }
     }
+    // the resolves are chained, so the last one completes the render; the caller's stream waits for it
+    if (n_lanes > 1 && last_lane != 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->lanes[last_lane].resolved, 0));
     c->stats.paths += (uint64_t)n_paths;
     if (work) return collect_work(c);
     return CPT_OK;
@@ -515,43 +574,34 @@ int cpt_trace_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, 
     return CPT_OK;
 }
 
-static int ensure_spill(cpt_ctx* c) {
-    if (c->extend_variant < 1 || c->spill_blocks >= c->pw_blocks) return CPT_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->d_spill) (void)hipFree(c->d_spill);
-    c->d_spill = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&c->d_spill, (size_t)(CPT_PW_STACK_MAX - CPT_PW_STACK_LDS_HOST) * (size_t)c->pw_blocks * CPT_PW_THREADS_HOST * sizeof(uint32_t)));
-    c->spill_blocks = c->pw_blocks;
-    return CPT_OK;
-}
-
 int cpt_extend_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, int32_t* h_tri, double* h_t) {
     if (!c || !h_o || !h_d || !h_tri || !h_t || n < 0) return c ? fail(c, CPT_EINVAL, "cpt_extend_rays: bad argument") : CPT_EINVAL;
     if (!c->has_scene) return fail(c, CPT_ENOSCENE, "cpt_extend_rays: no scene uploaded");
     if (n == 0) return CPT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_spill(c);
+    cpt_ctx::Lane& ln = c->lanes[0];
+    int rc = ensure_spill(c, ln, c->stream);
     if (rc) return rc;
-    rc = ensure_paths(c, (size_t)n);
+    rc = ensure_paths(c, ln, c->stream, (size_t)n);
     if (rc) return rc;
     const size_t N = (size_t)n;
     std::vector<double> soa(6 * N);  // the stream is structure-of-arrays by position
     for (size_t i = 0; i < N; ++i)
         for (int k = 0; k < 3; ++k) { soa[(size_t)k * N + i] = h_o[3 * i + k]; soa[(size_t)(3 + k) * N + i] = h_d[3 * i + k]; }
-    const RayStream& in = c->R[0];
+    const RayStream& in = ln.R[0];
     double* dst[6] = {in.ox, in.oy, in.oz, in.dx, in.dy, in.dz};
     for (int k = 0; k < 6; ++k) HIP_TRY(c, hipMemcpyAsync(dst[k], soa.data() + (size_t)k * N, N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    uint32_t* cursors = c->d_counters + (CPT_MAX_DEPTH + 2);
-    HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_counters, n, 1, c->stream));
+    uint32_t* cursors = ln.d_counters + (CPT_MAX_DEPTH + 2);
+    HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)ln.d_counters, n, 1, c->stream));
     HIP_TRY(c, hipMemsetAsync(cursors, 0, sizeof(uint32_t), c->stream));
     LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, c->pw_chunk, c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     unsigned long long* work = c->count_work ? c->d_work : nullptr;
-    if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, c->H, c->d_counters, cursors, c->d_spill, work);
-    else launch_extend(L, c->sc, in, c->H, c->d_counters, (long long)n, work);
+    if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, ln.d_counters, cursors, ln.d_spill, work);
+    else launch_extend(L, c->sc, in, ln.H, ln.d_counters, (long long)n, work);
     HIP_TRY(c, hipGetLastError());
     c->stats.launches_extend++;
-    HIP_TRY(c, hipMemcpyAsync(h_t, c->H.t, N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(h_tri, c->H.tri, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_t, ln.H.t, N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_tri, ln.H.tri, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (work) return collect_work(c);
     return CPT_OK;

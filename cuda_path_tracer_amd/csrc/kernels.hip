@@ -43,7 +43,7 @@ __device__ __forceinline__ void store_ray(const RayStream& R, uint32_t p, const 
 // the pace of the kernel, so the count is aggregated over the whole workgroup first.
 // Stands in for thrust::partition over whole path records (reference: src/improved_path_tracer.cu:321-324).
 // Must be reached by every thread of the workgroup; returns the position (valid when keep).
-#define CPT_SHADE_BLOCK 512
+#define CPT_SHADE_BLOCK 256
 #define CPT_SHADE_WAVES (CPT_SHADE_BLOCK / CPT_WAVE)
 __device__ __forceinline__ uint32_t block_claim(uint32_t* counter, bool keep) {
     __shared__ uint32_t s_off[CPT_SHADE_WAVES];

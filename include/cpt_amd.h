@@ -137,8 +137,10 @@ void cpt_destroy(cpt_ctx* ctx);
 const char* cpt_last_error(const cpt_ctx* ctx);
 /* Launch on this hipStream_t (passed as void*) instead of the context's own stream. */
 int cpt_set_stream(cpt_ctx* ctx, void* hip_stream);
-/* Tuning knobs, by name: "batch_paths" (path slots the wavefront pipeline keeps in flight,
- * default 2^23), "max_blocks" (grid cap of the grid-stride kernels, default 8 per CU),
+/* Tuning knobs, by name: "batch_paths" (path slots of one batch of the wavefront pipeline,
+ * default 2^23), "streams" (batches in flight at once, each on its own HIP stream, so that one
+ * batch's intersection kernel overlaps another's shading kernel; default 2, at most 4; the result
+ * does not depend on it), "max_blocks" (grid cap of the grid-stride kernels, default 8 per CU),
  * "extend_variant" (1: persistent waves with an LDS record cache, default; 0: one ray per thread;
  * 2: as 1 but walking the nearer child first and skipping boxes entered beyond the closest hit so
  * far -- a fast mode that returns the same hits without reproducing the reference's visit set),
