@@ -351,8 +351,18 @@ def test_every_pipeline_variant_gives_the_same_image(gpu_scene):
             g.render_into(acc.data_ptr(), g.params(w, h, 0, spp, depth))
             g.synchronize()
             images.append(acc.cpu().numpy())
+        # batches in flight on 1, 2 and 4 streams, with batches small enough that every lane is used
+        for streams in (1, 2, 4):
+            g.set_option("streams", streams)
+            g.set_option("batch_paths", 2 * 96 * 64)
+            acc = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+            g.render_into(acc.data_ptr(), g.params(w, h, 0, spp, depth))
+            g.synchronize()
+            images.append(acc.cpu().numpy())
     finally:
         g.set_option("extend_variant", 1)
+        g.set_option("streams", 2)
+        g.set_option("batch_paths", 1 << 23)
     for im in images[1:]:
         assert np.array_equal(bits(images[0]), bits(im))
 
