@@ -274,14 +274,31 @@ def test_edge_cases(gpu, host_scenes, oracle):
         gpu.render_image(gpu.params(16, 16, 0, 2, -1))
 
 
-def test_converged_image_against_reference_golden_luminance(gpu_scene):
-    """Soft known-answer: mean luminance of the reference's own 512x512 golden renders
-    (important_assets/Renders/benchmark-renders/bvh_renders/cornell-box.ray_3_{1024_cpu,3072_gpu}.png:
-    72.12 and 72.56 on the Rec.709 scale).  Tolerance +-1.0 of 255."""
-    g = gpu_scene("cornell-box")
-    img = g.render_image(g.params(512, 512, 0, 1024, 3)).astype(np.float64)
+def _golden_luminance_cases():
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    table = json.load(open(os.path.join(here, "golden", "luminance.json")))
+    cases = []
+    for scene, by_depth in sorted(table.items()):
+        if scene.startswith("_"):
+            continue
+        for depth, rows in sorted(by_depth.items()):
+            estimator, spp, lum = max(rows, key=lambda r: r[1])  # the best-converged golden render
+            cases.append(pytest.param(scene, int(depth), lum, id="%s-depth%s-%s%d" % (scene, depth, estimator, spp)))
+    return cases
+
+
+@pytest.mark.parametrize("scene,depth,golden", _golden_luminance_cases())
+def test_converged_image_against_reference_golden_luminance(scene, depth, golden, gpu_scene):
+    """Soft known-answer: mean Rec.709 luminance of the reference's own 512x512 golden renders
+    (important_assets/Renders/benchmark-renders/bvh_renders/{scene}.ray_{depth}_{spp}_{cpu|gpu}.png of
+    the reference, tabulated in tests/golden/luminance.json), for every scene and depth it holds:
+    diffuse, mirror and dielectric lobes at depths 3 to 7.  Tolerance +-1.0 of 255."""
+    g = gpu_scene(scene)
+    img = g.render_image(g.params(512, 512, 0, 1024, depth)).astype(np.float64)
     lum = (0.2126 * img[..., 0] + 0.7152 * img[..., 1] + 0.0722 * img[..., 2]).mean()
-    assert abs(lum - 72.12) < 1.0, lum
+    assert abs(lum - golden) < 1.0, (lum, golden)
 
 
 @pytest.mark.parametrize("name", ["cornell-box2", "cornell-box2-transmissive", "teapot-trans", "dragon-spec"])
