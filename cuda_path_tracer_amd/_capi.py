@@ -68,13 +68,15 @@ class Stats(C.Structure):
 
 assert C.sizeof(Node) == 128 and C.sizeof(Tri) == 128 and C.sizeof(TriNormals) == 72 and C.sizeof(Material) == 136
 
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)
+
 MODE_WAVEFRONT = 0
 MODE_MEGAKERNEL = 1
 
 # every symbol include/cpt_amd.h declares
 AMD_SYMBOLS = [
     "cpt_create", "cpt_destroy", "cpt_last_error", "cpt_set_stream", "cpt_set_option", "cpt_set_instrumentation",
-    "cpt_upload_scene", "cpt_render", "cpt_tonemap", "cpt_render_image", "cpt_synchronize", "cpt_get_stats",
+    "cpt_upload_scene", "cpt_render", "cpt_tonemap", "cpt_render_image", "cpt_render_progressive", "cpt_synchronize", "cpt_get_stats",
     "cpt_reset_stats", "cpt_extend_rays", "cpt_trace_rays", "cpt_camera_rays", "cpt_path_radiance", "cpt_probe_math", "cpt_probe_rng",
 ]
 # every symbol include/cpt_host.h declares
@@ -105,6 +107,7 @@ def amd():
         L.cpt_render.argtypes = [vp, C.POINTER(RenderParams), vp]
         L.cpt_tonemap.argtypes = [vp, vp, i32, i32, i32, vp]
         L.cpt_render_image.argtypes = [vp, C.POINTER(RenderParams), vp]
+        L.cpt_render_progressive.argtypes = [vp, C.POINTER(RenderParams), i32, vp, i32, vp, PROGRESS_FN, vp, C.POINTER(i32)]
         L.cpt_synchronize.argtypes = [vp]
         L.cpt_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.cpt_reset_stats.argtypes = [vp]

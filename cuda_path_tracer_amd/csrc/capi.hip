@@ -521,6 +521,53 @@ int cpt_render_image(cpt_ctx* c, const cpt_render_params* p, uint8_t* h_rgb) {
     return rc;
 }
 
+// device buffer that lives for one blocking call
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+
+int cpt_render_progressive(cpt_ctx* c, const cpt_render_params* p, int32_t chunk_spp, double* h_accum, int32_t accum_samples,
+                           uint8_t* h_rgb, cpt_progress_fn progress, void* user, int32_t* samples_done) {
+    if (samples_done) *samples_done = 0;
+    if (!c || !p || !h_rgb) return c ? fail(c, CPT_EINVAL, "cpt_render_progressive: NULL argument") : CPT_EINVAL;
+    if (p->sample_end <= p->sample_begin) return fail(c, CPT_EINVAL, "cpt_render_progressive: empty sample range");
+    if (p->width < 1 || p->height < 1) return fail(c, CPT_EINVAL, "bad image size");
+    if (chunk_spp < 1) return fail(c, CPT_EINVAL, "cpt_render_progressive: chunk_spp must be >= 1");
+    if (accum_samples < 0 || (accum_samples > 0 && !h_accum)) return fail(c, CPT_EINVAL, "cpt_render_progressive: accum_samples without h_accum");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)p->width * p->height * 3;
+    DevBuf accum, rgb;
+    HIP_TRY(c, accum.alloc(n * sizeof(double)));
+    HIP_TRY(c, rgb.alloc(n));
+    if (accum_samples > 0) HIP_TRY(c, hipMemcpyAsync(accum.p, h_accum, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    else HIP_TRY(c, hipMemsetAsync(accum.p, 0, n * sizeof(double), c->stream));
+    int rc = CPT_OK;
+    int done = 0;
+    for (int s = p->sample_begin; s < p->sample_end && rc == CPT_OK; s += chunk_spp) {
+        cpt_render_params q = *p;
+        q.sample_begin = s;
+        q.sample_end = std::min(p->sample_end, s + chunk_spp);
+        rc = cpt_render(c, &q, (double*)accum.p);
+        if (rc != CPT_OK) break;
+        done += q.sample_end - q.sample_begin;
+        rc = cpt_tonemap(c, (const double*)accum.p, p->width, p->height, accum_samples + done, (uint8_t*)rgb.p);
+        if (rc != CPT_OK) break;
+        hipError_t e = hipMemcpyAsync(h_rgb, rgb.p, n, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = fail(c, CPT_EHIP, "copy back: %s", hipGetErrorString(e)); break; }
+        if (progress && progress(user, accum_samples + done, h_rgb) != 0) break;
+    }
+    if (rc == CPT_OK && h_accum) {
+        hipError_t e = hipMemcpyAsync(h_accum, accum.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) rc = fail(c, CPT_EHIP, "copy back: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(c->stream);
+    if (samples_done) *samples_done = done;
+    return rc;
+}
+
 int cpt_synchronize(cpt_ctx* c) {
     if (!c) return CPT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -539,13 +586,8 @@ int cpt_reset_stats(cpt_ctx* c) {
     return CPT_OK;
 }
 
-// ---- parity hooks: small scratch buffers, blocking ---------------------------------------------
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
-};
 
+// ---- parity hooks: blocking, host arrays in and out ---------------------------------------------
 int cpt_trace_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, int32_t* h_tri, double* h_t,
                    double* h_normal, uint64_t* h_vhash, int32_t* h_counts, uint8_t* h_bitmap, int32_t stride) {
     if (!c || !h_o || !h_d || !h_tri || !h_t || n < 0) return c ? fail(c, CPT_EINVAL, "cpt_trace_rays: bad argument") : CPT_EINVAL;

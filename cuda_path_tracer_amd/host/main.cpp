@@ -24,9 +24,20 @@ struct Cli {
     int size = 512;     // reference default: src/ui/TraceUI.h:102
     int samples = 32;   // reference default: src/ui/CommandLineUI.cpp:30
     bool gpu = false;
-    std::string json, cubemap;
+    std::string json, cubemap, metrics;
     cpt::PathTracingOptions pt;
 };
+
+struct ProgressiveOutput {  // rewrites the output image while a long render runs
+    const char* name;
+};
+bool write_progress(void* user, int samples, const unsigned char* rgb, int w, int h) {
+    const ProgressiveOutput* po = (const ProgressiveOutput*)user;
+    std::string err;
+    if (!cpt::write_image(po->name, w, h, rgb, err)) std::cerr << err << std::endl;
+    std::cout << "  " << samples << " samples per pixel written to " << po->name << std::endl;
+    return false;
+}
 
 void usage(const char* prog, const Cli& c) {
     std::cerr << "usage: " << prog << " [options] [input.ray output.png]\n"
@@ -40,7 +51,10 @@ void usage(const char* prog, const Cli& c) {
               << "  --dof <focal>,<aperture>   thin-lens camera\n"
               << "  --rr        Russian roulette\n"
               << "  --seed <#>  random seed (default 1984)\n"
-              << "  --device <#> GPU ordinal (default 0)\n";
+              << "  --device <#> GPU ordinal (default 0)\n"
+              << "  --progressive <#>   rewrite the output image every # samples per pixel\n"
+              << "  --checkpoint <FILE> resume from FILE if it matches this render, and save the radiance sums to it\n"
+              << "  --metrics <FILE>    write timing and work counters as JSON\n";
 }
 
 // Flat JSON object with numeric values: the keys the reference reads that matter here are
@@ -64,7 +78,9 @@ int main(int argc, char** argv) {
     Cli c;
     static option longopts[] = {{"mode", required_argument, nullptr, 1000}, {"dof", required_argument, nullptr, 1001},
                                 {"rr", no_argument, nullptr, 1002},         {"seed", required_argument, nullptr, 1003},
-                                {"device", required_argument, nullptr, 1004}, {nullptr, 0, nullptr, 0}};
+                                {"device", required_argument, nullptr, 1004}, {"progressive", required_argument, nullptr, 1005},
+                                {"checkpoint", required_argument, nullptr, 1006}, {"metrics", required_argument, nullptr, 1007},
+                                {nullptr, 0, nullptr, 0}};
     int o;
     while ((o = getopt_long(argc, argv, "tr:w:hj:c:gs:", longopts, nullptr)) != -1) {
         switch (o) {
@@ -88,6 +104,9 @@ int main(int argc, char** argv) {
             case 1002: c.pt.russian_roulette = true; break;
             case 1003: c.pt.seed = strtoull(optarg, nullptr, 10); break;
             case 1004: c.pt.device = atoi(optarg); break;
+            case 1005: c.pt.progressive_spp = atoi(optarg); break;
+            case 1006: c.pt.checkpoint = optarg; break;
+            case 1007: c.metrics = optarg; break;
             default:
                 std::cerr << "Invalid argument: '" << o << "'." << std::endl;
                 usage(argv[0], c);
@@ -109,6 +128,8 @@ int main(int argc, char** argv) {
     const char* rayName = argv[optind];
     const char* imgName = argv[optind + 1];
 
+    ProgressiveOutput po{imgName};
+    if (c.pt.progressive_spp > 0) { c.pt.on_progress = write_progress; c.pt.progress_user = &po; }
     cpt::RayTracer rt;
     rt.options = c.pt;
     if (!rt.loadScene(rayName)) {
@@ -135,5 +156,18 @@ int main(int argc, char** argv) {
         return 3;
     }
     std::cout << "total time = " << secs << " seconds, " << (double)width * height * c.samples / secs / 1e6 << " Mpaths/s" << std::endl;
+    if (!c.metrics.empty()) {
+        cpt_stats st{};
+        rt.stats(st);
+        std::ofstream m(c.metrics);
+        m << "{\"scene\": \"" << rayName << "\", \"width\": " << width << ", \"height\": " << height
+          << ", \"samples_requested\": " << c.samples << ", \"samples_in_image\": " << rt.samplesInImage()
+          << ", \"depth\": " << c.depth << ", \"mode\": \"" << (c.pt.work_queue ? "wavefront" : "mega") << "\""
+          << ", \"seconds\": " << secs << ", \"paths\": " << st.paths
+          << ", \"mpaths_per_s\": " << (secs > 0 ? (double)st.paths / secs / 1e6 : 0.0)
+          << ", \"launches\": {\"generate\": " << st.launches_generate << ", \"extend\": " << st.launches_extend
+          << ", \"shade\": " << st.launches_shade << ", \"mega\": " << st.launches_mega << "}}" << std::endl;
+        if (!m) { std::cerr << "cannot write " << c.metrics << std::endl; return 3; }
+    }
     return 0;
 }

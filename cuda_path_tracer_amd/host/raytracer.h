@@ -20,6 +20,11 @@ struct PathTracingOptions {  // what the reference hard-codes in traceImageGPU (
     bool work_queue = true;  // true: betterPathTracing (wavefront); false: traceImageGPU (one thread per pixel)
     unsigned long long seed = 1984;
     int device = 0;
+    // long renders (no counterpart in the reference)
+    int progressive_spp = 0;        // > 0: refresh the image every this many samples and call on_progress
+    std::string checkpoint;         // non-empty: resume from this file if it matches, and save the sums to it
+    bool (*on_progress)(void* user, int samples, const unsigned char* rgb, int w, int h) = nullptr;  // true = stop
+    void* progress_user = nullptr;
 };
 
 class RayTracer {
@@ -40,6 +45,8 @@ public:
 
     PathTracingOptions options;
     const std::string& lastError() const { return error_; }
+    int samplesInImage() const { return samples_in_image_; }  // differs from the request after a resume or an early stop
+    bool stats(cpt_stats& out) const { return ctx_ && cpt_get_stats(ctx_, &out) == CPT_OK; }
     bool failed() const { return !error_.empty(); }
 
 private:
@@ -50,7 +57,7 @@ private:
     std::vector<unsigned char> buffer_;
     int buffer_width_ = 0, buffer_height_ = 0;
     bool useGPU_ = false;
-    int samples_per_pixel_ = 32, depth_ = 0;
+    int samples_per_pixel_ = 32, depth_ = 0, samples_in_image_ = 0;
     std::string error_;
 };
 

@@ -89,6 +89,23 @@ class Renderer:
     def synchronize(self):
         self._check(self._L.cpt_synchronize(self._h), "cpt_synchronize")
 
+    def render_progressive(self, params, chunk_spp, accum=None, accum_samples=0, on_progress=None):
+        """cpt_render_progressive: returns (rgb (h, w, 3) uint8, samples this call added).  `accum`, a
+        float64 array (h, w, 3), carries the radiance sums between calls (resume / checkpoint);
+        on_progress(samples_in_image, rgb_view) may return True to stop."""
+        rgb = np.zeros((params.height, params.width, 3), np.uint8)
+        if accum is not None:
+            assert accum.dtype == np.float64 and accum.flags.c_contiguous and accum.shape == rgb.shape
+
+        def cb(_user, samples, _ptr):
+            return 1 if (on_progress is not None and on_progress(samples, rgb)) else 0
+        fn = _capi.PROGRESS_FN(cb)
+        done = C.c_int32(0)
+        self._check(self._L.cpt_render_progressive(self._h, C.byref(params), int(chunk_spp),
+                                                   accum.ctypes.data if accum is not None else None, int(accum_samples),
+                                                   rgb.ctypes.data, fn, None, C.byref(done)), "cpt_render_progressive")
+        return rgb, done.value
+
     def stats(self):
         s = _capi.Stats()
         self._check(self._L.cpt_get_stats(self._h, C.byref(s)), "cpt_get_stats")

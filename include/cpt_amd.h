@@ -175,6 +175,22 @@ int cpt_tonemap(cpt_ctx* ctx, const double* d_accum, int32_t width, int32_t heig
  * Replaces RayTracer::traceImageGPU(w, h) (reference: src/path_tracer.cu:507-551). */
 int cpt_render_image(cpt_ctx* ctx, const cpt_render_params* params, uint8_t* h_rgb);
 
+/* cpt_render_image in chunks, for long renders: after every `chunk_spp` samples (and at the end) the
+ * image so far is tonemapped, copied into h_rgb and `progress` (nullable) is called with the number of
+ * samples the image now holds; a non-zero return from it stops the render (the call then returns
+ * CPT_OK with what was accumulated).  h_accum (nullable; host, width*height*3 doubles) makes the
+ * render resumable: on entry it holds the radiance sums of the `accum_samples` samples
+ * [params->sample_begin - accum_samples, params->sample_begin) of an earlier call (ignored when
+ * accum_samples is 0), on return the sums including this call's samples.  Because a sample's paths
+ * depend only on (pixel, sample index, seed), a render resumed this way is bit-identical to one
+ * made in a single call.  *samples_done (nullable) receives the samples this call added.  Blocking.
+ * No counterpart in the reference, whose render is one blocking kernel launch
+ * (src/path_tracer.cu:543-550). */
+typedef int (*cpt_progress_fn)(void* user, int32_t samples_in_image, const uint8_t* h_rgb);
+int cpt_render_progressive(cpt_ctx* ctx, const cpt_render_params* params, int32_t chunk_spp, double* h_accum,
+                           int32_t accum_samples, uint8_t* h_rgb, cpt_progress_fn progress, void* user,
+                           int32_t* samples_done);
+
 /* Wait for everything queued on the context's stream. */
 int cpt_synchronize(cpt_ctx* ctx);
 int cpt_get_stats(cpt_ctx* ctx, cpt_stats* out);
