@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--mode", default="wavefront", choices=["wavefront", "mega"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-paths", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=0, help="batches in flight at once (library default when 0)")
     args = ap.parse_args()
 
     import torch
@@ -111,7 +112,10 @@ def main():
 
     wl = WORKLOADS[args.workload]
     mode = MODE_WAVEFRONT if args.mode == "wavefront" else MODE_MEGAKERNEL
-    stream = torch.cuda.current_stream()
+    # a stream of our own: the legacy default stream serialises against every other stream of the process,
+    # which would keep the renderer's second lane from overlapping the first
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     renderers = []
     for name in wl["scenes"]:
         hs = HostScene(scene_file(name))
@@ -119,6 +123,8 @@ def main():
         r.set_stream(stream.cuda_stream)
         if args.batch_paths:
             r.set_option("batch_paths", args.batch_paths)
+        if args.streams:
+            r.set_option("streams", args.streams)
         r.upload(hs)
         w = wl["width"]
         h = hs.height_for_width(w)

@@ -113,7 +113,7 @@ int cpt_create(int device, cpt_ctx** out) {
     if (e != hipSuccess) { delete c; return fail(nullptr, CPT_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
     c->max_blocks = prop.multiProcessorCount * 8;
     c->pw_blocks = prop.multiProcessorCount;
-    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamDefault);
     if (e != hipSuccess) { delete c; return fail(nullptr, CPT_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
     for (int k = 0; k < CPT_MAX_LANES && e == hipSuccess; ++k) {
@@ -154,7 +154,7 @@ const char* cpt_last_error(const cpt_ctx* c) { return c ? c->err.c_str() : g_cre
 
 int cpt_set_stream(cpt_ctx* c, void* s) {
     if (!c) return CPT_EINVAL;
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = s == CPT_OWN_STREAM ? c->own_stream : (hipStream_t)s;
     return CPT_OK;
 }
 

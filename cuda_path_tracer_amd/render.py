@@ -51,7 +51,10 @@ class Renderer:
 
     # --- configuration ------------------------------------------------------------------------
     def set_stream(self, hip_stream_ptr):
-        self._check(self._L.cpt_set_stream(self._h, C.c_void_p(hip_stream_ptr)), "cpt_set_stream")
+        """Launch on this hipStream_t (an integer handle, e.g. torch.cuda.Stream().cuda_stream; 0 is the
+        legacy default stream).  None goes back to the context's own stream."""
+        ptr = C.c_void_p(-1) if hip_stream_ptr is None else C.c_void_p(hip_stream_ptr)
+        self._check(self._L.cpt_set_stream(self._h, ptr), "cpt_set_stream")
 
     def set_option(self, key, value):
         self._check(self._L.cpt_set_option(self._h, key.encode(), int(value)), "cpt_set_option")

@@ -135,7 +135,11 @@ int cpt_create(int device, cpt_ctx** out);
 void cpt_destroy(cpt_ctx* ctx);
 /* Text of the last error on this context (ctx may be NULL: error of the last failed cpt_create). */
 const char* cpt_last_error(const cpt_ctx* ctx);
-/* Launch on this hipStream_t (passed as void*) instead of the context's own stream. */
+/* Launch on this hipStream_t (passed as void*) instead of the context's own stream.  As everywhere
+ * in HIP, NULL is the legacy default stream; CPT_OWN_STREAM goes back to the context's own stream,
+ * which is an ordinary (blocking) stream: it is ordered after work queued earlier on the legacy
+ * default stream, so buffers prepared there can be handed to cpt_render without a fence. */
+#define CPT_OWN_STREAM ((void*)-1)
 int cpt_set_stream(cpt_ctx* ctx, void* hip_stream);
 /* Tuning knobs, by name: "batch_paths" (path slots of one batch of the wavefront pipeline,
  * default 2^23), "streams" (batches in flight at once, each on its own HIP stream, so that one
