@@ -106,10 +106,24 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
+    # CPT_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then share GPUs)
+    backend = os.environ.get("CPT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
+    verbose = bool(os.environ.get("CPT_BENCH_VERBOSE"))
+
+    def say(msg):
+        if verbose:
+            print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
+
+    say("process group up, backend %s, device %d" % (backend if world > 1 else "-", local_rank))
     wl = WORKLOADS[args.workload]
     mode = MODE_WAVEFRONT if args.mode == "wavefront" else MODE_MEGAKERNEL
     # a stream of our own: the legacy default stream serialises against every other stream of the process,
@@ -134,11 +148,12 @@ def main():
     spp = wl["spp"]
     s0, s1 = rank * spp, (rank + 1) * spp  # weak scaling: every rank adds `spp` new sample indices
 
-    def step():
+    def step(collective=True):
         for (r, hs, w, h, acc, rgb) in renderers:
             acc.zero_()
             r.render_into(acc.data_ptr(), r.params(w, h, s0, s1, wl["depth"], mode=mode))
-            reduce_radiance(acc, dst=0)
+            if collective:
+                reduce_radiance(acc, dst=0)
             if rank == 0:
                 r.tonemap_into(acc.data_ptr(), w, h, spp * world, rgb.data_ptr())
 
@@ -148,16 +163,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    say("scenes uploaded")
     for _ in range(args.warmup):
         step()
+        say("warmup step queued")
     fence()
+    say("warmup done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    say("timed steps done in %.3f s" % elapsed)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -171,13 +190,13 @@ def main():
         for (r, *_rest) in renderers:
             r.reset_stats()
             r.set_instrumentation(time_kernels=True, count_work=False)
-        step()
+        step(collective=False)  # rank 0 alone: the other ranks are already at the final barrier
         torch.cuda.synchronize()
         timed = [r.stats() for (r, *_rest) in renderers]
         for (r, *_rest) in renderers:
             r.reset_stats()
             r.set_instrumentation(time_kernels=False, count_work=True)
-        step()
+        step(collective=False)
         torch.cuda.synchronize()
         counted = [r.stats() for (r, *_rest) in renderers]
         for (r, *_rest) in renderers:

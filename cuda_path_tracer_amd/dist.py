@@ -23,5 +23,11 @@ def reduce_radiance(accum, dst=0, group=None):
     w*h*3 float64 per render."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if accum.is_cuda and dist.get_backend(group) == "gloo":
+            # gloo reduces host tensors only: stage through the host (rehearsals on boxes without RCCL peers)
+            host = accum.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+            accum.copy_(host)
+        else:
+            dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return accum

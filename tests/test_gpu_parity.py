@@ -452,3 +452,30 @@ def test_cli_progressive_checkpoint_and_metrics(tmp_path):
     # a checkpoint of another render (different depth) is ignored, not mixed in
     r = subprocess.run([exe, "-g", "-r", "2", "-w", "72", "-s", "3", "--checkpoint", ck, scene, two], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "ignoring" in r.stdout
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 under torch.distributed.run, rehearsed on one GPU (both ranks share it; gloo stands
+    in for RCCL, which refuses two ranks on one device): the N > 1 path -- sample sharding, the reduce,
+    the max-over-ranks timing, rank 0's solo instrumentation steps, the final barrier -- runs to the end
+    and prints one JSON line."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CPT_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--workload", "cornell2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["config"]["paths_per_step"] == 2 * 512 * 512 * 16
