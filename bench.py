@@ -21,13 +21,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
 
 WORKLOADS = {
-    # BASELINE.json configs[1]
+    # the headline configuration: both mixed-lobe Cornell boxes at 512x512, 256 spp, depth 8
     "cfg2": dict(desc="cornell-box2-specular + cornell-box2-transmissive, 512x512, 256 spp, depth 8",
                  scenes=["cornell-box2-specular", "cornell-box2-transmissive"], width=512, spp=256, depth=8),
-    # BASELINE.json configs[2]
+    # the large-mesh configuration
     "dragon": dict(desc="dragon-spec, 1024x1024, 1024 spp, depth 8", scenes=["dragon-spec"], width=1024, spp=1024,
                    depth=8),
-    # BASELINE.json configs[0] shape on the GPU
+    # the size the reference's CPU estimator can run
     "cornell2": dict(desc="cornell-box2, 512x512, 16 spp, depth 5", scenes=["cornell-box2"], width=512, spp=16,
                      depth=5),
 }
