@@ -60,11 +60,9 @@ def gpu():
 
 @pytest.fixture(scope="session")
 def gpu_scene(gpu, host_scenes):
-    state = {"name": None}
-
     def use(name):
-        if state["name"] != name:
-            gpu.upload(host_scenes(name))
-            state["name"] = name
+        hs = host_scenes(name)
+        if getattr(gpu, "_scene", None) is not hs:  # also true after a test uploaded a scene of its own
+            gpu.upload(hs)
         return gpu
     return use

@@ -479,3 +479,42 @@ def test_bench_two_ranks_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["config"]["paths_per_step"] == 2 * 512 * 512 * 16
+
+
+def test_deep_stacks_spill_past_the_lds_entries(tmp_path, gpu, oracle):
+    """A row of 3000 triangles facing down the x axis, spaced geometrically: the SAH tree is 22 levels
+    tall and a ray along the axis has up to 15 postponed siblings, more than the 12 stack entries the
+    persistent extend kernel keeps in LDS, so its global-memory spill columns are used."""
+    from cuda_path_tracer_amd import HostScene
+    pts, faces = [], []
+    x, dx = 0.0, 0.001
+    for i in range(3000):
+        pts += ["(%r,-1,-1)" % x, "(%r,1,-1)" % x, "(%r,0,1)" % x]
+        faces.append("(%d,%d,%d)" % (3 * i, 3 * i + 1, 3 * i + 2))
+        x += dx
+        dx *= 1.003
+    text = ("SBT-raytracer 1.0\ncamera { position = (-5,0,0); viewdir = (1,0,0); updir = (0,1,0); }\n"
+            "polymesh { material = { diffuse = (0.5,0.5,0.5); transmissive = (0.5,0.5,0.5); index = 1.0; };\n"
+            " points = (%s); faces = (%s); }\n" % (",".join(pts), ",".join(faces)))
+    path = tmp_path / "cards.ray"
+    path.write_text(text)
+    orc = oracle.OracleScene(str(path))
+    hs = HostScene(str(path))
+    assert hs.desc.tree_height >= 20
+    gpu.upload(hs)
+    rng = np.random.default_rng(2)
+    n = 4000
+    o = np.column_stack([np.full(n, -5.0), rng.uniform(-0.9, 0.9, n), rng.uniform(-0.9, 0.9, n)])
+    d = np.column_stack([np.ones(n), rng.normal(0, 0.02, n), rng.normal(0, 0.02, n)])
+    o[n // 2:, 0] = x + 5.0  # half of them from the far side, against the face normals
+    d[n // 2:, 0] = -1.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    want = _compare_trace(gpu, orc, o, d, bitmap=False)
+    assert int(want["max_stack"].max()) > 12
+    try:
+        for variant in (1, 0, 2):
+            gpu.set_option("extend_variant", variant)
+            tri, t = gpu.extend_rays(o, d)
+            assert np.array_equal(tri, want["prim"]) and np.array_equal(bits(t), bits(want["t"])), variant
+    finally:
+        gpu.set_option("extend_variant", 1)
