@@ -518,3 +518,51 @@ def test_deep_stacks_spill_past_the_lds_entries(tmp_path, gpu, oracle):
             assert np.array_equal(tri, want["prim"]) and np.array_equal(bits(t), bits(want["t"])), variant
     finally:
         gpu.set_option("extend_variant", 1)
+
+
+def test_malformed_scenes_are_refused_at_upload(gpu, host_scenes):
+    """The kernels index the scene arrays unchecked, so cpt_upload_scene must refuse a scene whose
+    structure is broken, with a message, and leave the context usable."""
+    import ctypes as C
+    from cuda_path_tracer_amd import CptError, _capi
+    hs = host_scenes("cornell-box2")
+    base_nodes, base_tris, base_norm, base_mats = hs.nodes(), hs.tris(), hs.tri_normals(), hs.materials()
+
+    class Shim:  # what Renderer.upload needs: .desc, with the arrays kept alive beside it
+        pass
+
+    def build(nodes, tris, **over):
+        s = Shim()
+        s.keep = (np.ascontiguousarray(nodes), np.ascontiguousarray(tris), np.ascontiguousarray(base_norm), np.ascontiguousarray(base_mats))
+        d = _capi.SceneDesc()
+        C.memmove(C.byref(d), C.byref(hs.desc), C.sizeof(d))
+        d.nodes = C.cast(s.keep[0].ctypes.data, C.POINTER(_capi.Node))
+        d.tris = C.cast(s.keep[1].ctypes.data, C.POINTER(_capi.Tri))
+        d.tri_normals = C.cast(s.keep[2].ctypes.data, C.POINTER(_capi.TriNormals))
+        d.materials = C.cast(s.keep[3].ctypes.data, C.POINTER(_capi.Material))
+        for k, v in over.items():
+            setattr(d, k, v)
+        s.desc = d
+        return s
+
+    gpu.upload(build(base_nodes, base_tris))  # the untouched copy is accepted
+    cases = []
+    n = base_nodes.copy(); n["lref"][0] = len(n) + 5; cases.append((build(n, base_tris), "child record"))
+    n = base_nodes.copy(); n["rref"][1] = 0; cases.append((build(n, base_tris), "not after its parent"))
+    n = base_nodes.copy()
+    leaves = [(k, f) for k in range(len(n)) for f in ("lref", "rref") if n[f][k] < 0]
+    (k0, f0), (k1, f1) = leaves[0], leaves[1]
+    n[f1][k1] = n[f0][k0]; cases.append((build(n, base_tris), "two leaves"))
+    n = base_nodes.copy(); n["lbox"][2][1] = np.inf; cases.append((build(n, base_tris), "not finite"))
+    n = base_nodes.copy(); n["rid"][0] = 10 ** 6; cases.append((build(n, base_tris), "canonical id"))
+    t = base_tris.copy(); t["material"][3] = 99; cases.append((build(base_nodes, t), "bad material"))
+    cases.append((build(base_nodes, base_tris, n_nodes=hs.n_nodes - 1), "n_nodes"))
+    cases.append((build(base_nodes, base_tris, tree_height=64), "stack"))
+    for scene, needle in cases:
+        with pytest.raises(CptError) as e:
+            gpu.upload(scene)
+        assert needle in str(e.value), (needle, str(e.value))
+    # still usable
+    gpu.upload(hs)
+    img = gpu.render_image(gpu.params(16, 16, 0, 2, 2))
+    assert img.shape == (16, 16, 3)
