@@ -209,8 +209,6 @@ static int validate_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     if (s->n_nodes != s->n_tris - 1) return fail(c, CPT_EINVAL, "n_nodes (%d) != n_tris - 1 (%d)", s->n_nodes, s->n_tris - 1);
     if (s->n_nodes > 0 && !s->nodes) return fail(c, CPT_EINVAL, "nodes missing");
     if (s->n_tree_nodes != 2 * s->n_tris - 1) return fail(c, CPT_EINVAL, "n_tree_nodes must be 2*n_tris-1");
-    if (s->tree_height - 2 > CPT_STACK_ENTRIES_HOST)
-        return fail(c, CPT_ELIMIT, "tree height %d needs a %d-entry stack; limit is %d", s->tree_height, s->tree_height - 2, CPT_STACK_ENTRIES_HOST);
     for (int i = 0; i < s->n_tris; ++i)
         if (s->tris[i].material < 0 || s->tris[i].material >= s->n_materials) return fail(c, CPT_EINVAL, "triangle %d: bad material", i);
     std::vector<unsigned char> seen_tri((size_t)s->n_tris, 0), seen_node((size_t)std::max(s->n_nodes, 1), 0);
@@ -232,6 +230,19 @@ static int validate_scene(cpt_ctx* c, const cpt_scene_desc* s) {
             }
         }
     }
+    // The traversal stacks are sized for a maximum tree height; measure it rather than trust the
+    // caller's figure (records come after their parents, so one forward pass finds every depth).
+    std::vector<int> level((size_t)std::max(s->n_nodes, 1), 1);
+    int levels = s->n_nodes > 0 ? 1 : 0;  // levels of internal nodes
+    for (int k = 0; k < s->n_nodes; ++k) {
+        const int refs[2] = {s->nodes[k].lref, s->nodes[k].rref};
+        for (int q = 0; q < 2; ++q)
+            if (refs[q] >= 0) { level[(size_t)refs[q]] = level[(size_t)k] + 1; levels = std::max(levels, level[(size_t)k] + 1); }
+    }
+    const int height = levels + 1;  // plus the leaf level
+    if (height - 2 > CPT_STACK_ENTRIES_HOST || s->tree_height - 2 > CPT_STACK_ENTRIES_HOST)
+        return fail(c, CPT_ELIMIT, "tree height %d needs a %d-entry stack; limit is %d", std::max(height, s->tree_height),
+                    std::max(height, s->tree_height) - 2, CPT_STACK_ENTRIES_HOST);
     return CPT_OK;
 }
 

@@ -558,6 +558,25 @@ def test_malformed_scenes_are_refused_at_upload(gpu, host_scenes):
     t = base_tris.copy(); t["material"][3] = 99; cases.append((build(base_nodes, t), "bad material"))
     cases.append((build(base_nodes, base_tris, n_nodes=hs.n_nodes - 1), "n_nodes"))
     cases.append((build(base_nodes, base_tris, tree_height=64), "stack"))
+    # a 40-triangle chain (every right child is the next node) is 40 levels tall whatever tree_height claims
+    m = 40
+    chain = np.zeros(m - 1, base_nodes.dtype)
+    for k in range(m - 1):
+        chain["lbox"][k] = chain["rbox"][k] = (0, 0, 0, 1, 1, 1)
+        chain["lref"][k] = ~k
+        chain["rref"][k] = k + 1 if k + 1 < m - 1 else ~(m - 1)
+        chain["lid"][k], chain["rid"][k], chain["self_id"][k] = 2 * k + 1, 2 * k + 2, 2 * k
+    tall = Shim()
+    tall.keep = (chain, np.repeat(base_tris[:1], m), np.repeat(base_norm[:1], m), np.ascontiguousarray(base_mats))
+    d = _capi.SceneDesc()
+    C.memmove(C.byref(d), C.byref(hs.desc), C.sizeof(d))
+    d.n_nodes, d.n_tris, d.n_tree_nodes, d.tree_height = m - 1, m, 2 * m - 1, 5
+    d.nodes = C.cast(tall.keep[0].ctypes.data, C.POINTER(_capi.Node))
+    d.tris = C.cast(tall.keep[1].ctypes.data, C.POINTER(_capi.Tri))
+    d.tri_normals = C.cast(tall.keep[2].ctypes.data, C.POINTER(_capi.TriNormals))
+    d.materials = C.cast(tall.keep[3].ctypes.data, C.POINTER(_capi.Material))
+    tall.desc = d
+    cases.append((tall, "tree height 40"))
     for scene, needle in cases:
         with pytest.raises(CptError) as e:
             gpu.upload(scene)
