@@ -287,8 +287,10 @@ __device__ __forceinline__ void draw2(const DParams& P, uint32_t pixel, uint32_t
 __device__ __forceinline__ void camera_ray(const cpt_camera& cam, double x, double y, dvec3& o, dvec3& d) {
     x -= 0.5;
     y -= 0.5;
-    d = normalize(dv(cam.look) + x * dv(cam.u) + y * dv(cam.v));
-    o = dv(cam.eye);
+    // element by element: taking the address of a by-value kernel argument would send it through scratch memory
+    const dvec3 look = dv(cam.look[0], cam.look[1], cam.look[2]), u = dv(cam.u[0], cam.u[1], cam.u[2]), v = dv(cam.v[0], cam.v[1], cam.v[2]);
+    d = normalize(look + x * u + y * v);
+    o = dv(cam.eye[0], cam.eye[1], cam.eye[2]);
 }
 
 // First ray of sample `sample` of pixel (i, j).
@@ -308,7 +310,8 @@ __device__ __forceinline__ void first_ray(const DScene& sc, const DParams& P, in
         double iShift = ja, jShift = jb;
         iShift *= (2 * P.aperture) - P.aperture;
         jShift *= (2 * P.aperture) - P.aperture;
-        dvec3 eye = dv(sc.cam.eye) + dv(sc.cam.u) * iShift + dv(sc.cam.v) * jShift;
+        const cpt_camera& cam = sc.cam;
+        dvec3 eye = dv(cam.eye[0], cam.eye[1], cam.eye[2]) + dv(cam.u[0], cam.u[1], cam.u[2]) * iShift + dv(cam.v[0], cam.v[1], cam.v[2]) * jShift;
         o = eye;
         d = normalize(focal - eye);
     }

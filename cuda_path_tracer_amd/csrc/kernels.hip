@@ -80,20 +80,29 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_generate(DScene sc, DParams P, Ra
         int k = slot / P.n_pix_slots, ps = slot - k * P.n_pix_slots;
         int i, j;
         bool live = slot_to_pixel(P, ps, i, j);
-        PathRegs s;
-        s.medium = 1.0;
-        s.atten = dv(1, 1, 1);
+        dvec3 o = dv(1e300, 1e300, 1e300), d = dv(1, 0, 0), atten = dv(0, 0, 0);
         if (live) {
             int sample = batch_s0 + k;
-            first_ray(sc, P, i, j, sample, s.o, s.d);
-            live = roulette(P, (uint32_t)(i + j * P.w), (uint32_t)sample, 0, s);
+            first_ray(sc, P, i, j, sample, o, d);
+            atten = dv(1, 1, 1);
+            if (P.rr) {  // roulette before the first segment, as before every other one
+                PathRegs s;
+                s.atten = atten;
+                live = roulette(P, (uint32_t)(i + j * P.w), (uint32_t)sample, 0, s);
+                atten = s.atten;
+            }
         }
         if (!live) {
-            s.o = dv(1e300, 1e300, 1e300);
-            s.d = dv(1, 0, 0);
-            s.atten = dv(0, 0, 0);
+            o = dv(1e300, 1e300, 1e300);
+            d = dv(1, 0, 0);
+            atten = dv(0, 0, 0);
         }
-        store_ray(out, (uint32_t)slot, s, (uint32_t)slot);
+        const uint32_t p = (uint32_t)slot;
+        out.ox[p] = o.x; out.oy[p] = o.y; out.oz[p] = o.z;
+        out.dx[p] = d.x; out.dy[p] = d.y; out.dz[p] = d.z;
+        out.medium[p] = 1.0;
+        out.ax[p] = atten.x; out.ay[p] = atten.y; out.az[p] = atten.z;
+        out.slot[p] = p;
         col.cx[slot] = 0.0; col.cy[slot] = 0.0; col.cz[slot] = 0.0;
     }
 }
