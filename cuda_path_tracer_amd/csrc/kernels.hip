@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
 #define CPT_PW_CACHE_RECORDS 512  // 64 KB of 128-byte records
 #define CPT_PW_STACK_LDS 12
 static_assert(CPT_PW_STACK_LDS == CPT_PW_STACK_LDS_HOST, "stack split must match the spill buffer sizing");
+#define CPT_PW_BOX_REPEAT 2   // node expansions per lane and loop turn
 #define CPT_PW_LEAF_CAP 10    // parked leaves per lane (a node expansion adds at most two)
 
 struct Rec7 {  // the first seven 16-byte pieces of a 128-byte record
@@ -279,52 +280,57 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
             continue;
         }
 
-        // ---- box phase: expand one node per lane that has one (and room to park two more leaves) ----
-        if (COUNT) {
-            uint64_t boxing = __ballot(node >= 0 && lp <= CPT_PW_LEAF_CAP - 2);
-            if (lane == 0 && boxing) box_passes++;
-        }
-        if (node >= 0 && lp <= CPT_PW_LEAF_CAP - 2) {
-            Rec7 r = fetch_record(sc.nodes, cache, 0, cached_nodes, node);
-            int2 refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));  // lref, rref
-            bool sure_l, sure_r;
-            double enter_l, enter_r;
-            bool hl = slab_filtered(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, sr, sure_l, enter_l);
-            bool hr = slab_filtered(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, sr, sure_r, enter_r);
-            if (sr.exact_only || !(sure_l && sure_r)) {
-                if (COUNT) exact++;
-                hl = slab_hit(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, d, enter_l);
-                hr = slab_hit(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, d, enter_r);
+        // ---- box phase: expand up to CPT_PW_BOX_REPEAT nodes per lane that has one (and room to park two more leaves) ----
+        // (several expansions per turn of the loop spread its fixed costs -- ballots, refill and triangle-pass
+        // decisions -- over more node steps)
+#pragma unroll
+        for (int rep = 0; rep < CPT_PW_BOX_REPEAT; ++rep) {
+            if (COUNT) {
+                uint64_t boxing = __ballot(node >= 0 && lp <= CPT_PW_LEAF_CAP - 2);
+                if (lane == 0 && boxing) box_passes++;
             }
-            if (CULL) {
-                if (best_t >= 0) {
-                    const double limit = best_t * 1.000001 + 1e-9;
-                    hl = hl && !(enter_l > limit);
-                    hr = hr && !(enter_r > limit);
+            if (node >= 0 && lp <= CPT_PW_LEAF_CAP - 2) {
+                Rec7 r = fetch_record(sc.nodes, cache, 0, cached_nodes, node);
+                int2 refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));  // lref, rref
+                bool sure_l, sure_r;
+                double enter_l, enter_r;
+                bool hl = slab_filtered(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, sr, sure_l, enter_l);
+                bool hr = slab_filtered(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, sr, sure_r, enter_r);
+                if (sr.exact_only || !(sure_l && sure_r)) {
+                    if (COUNT) exact++;
+                    hl = slab_hit(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, d, enter_l);
+                    hr = slab_hit(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, d, enter_r);
                 }
-                if (hl && hr && refs.x >= 0 && refs.y >= 0 && enter_r < enter_l) {  // nearer child first
-                    int tmp = refs.x; refs.x = refs.y; refs.y = tmp;
+                if (CULL) {
+                    if (best_t >= 0) {
+                        const double limit = best_t * 1.000001 + 1e-9;
+                        hl = hl && !(enter_l > limit);
+                        hr = hr && !(enter_r > limit);
+                    }
+                    if (hl && hr && refs.x >= 0 && refs.y >= 0 && enter_r < enter_l) {  // nearer child first
+                        int tmp = refs.x; refs.x = refs.y; refs.y = tmp;
+                    }
                 }
-            }
-            if (COUNT) steps++;
-            if (hl && refs.x < 0) { my_leaves[lp * CPT_WAVE] = (uint32_t)(~refs.x); ++lp; }
-            if (hr && refs.y < 0) { my_leaves[lp * CPT_WAVE] = (uint32_t)(~refs.y); ++lp; }
-            bool tl = hl && refs.x >= 0, tr = hr && refs.y >= 0;
-            if (tl) {
-                node = refs.x;
-                if (tr) {
-                    if (sp < CPT_PW_STACK_LDS) my_nodes[sp * CPT_WAVE] = (uint32_t)refs.y;
-                    else my_spill[(size_t)(sp - CPT_PW_STACK_LDS) * spill_stride] = (uint32_t)refs.y;
-                    ++sp;
+                if (COUNT) steps++;
+                if (hl && refs.x < 0) { my_leaves[lp * CPT_WAVE] = (uint32_t)(~refs.x); ++lp; }
+                if (hr && refs.y < 0) { my_leaves[lp * CPT_WAVE] = (uint32_t)(~refs.y); ++lp; }
+                bool tl = hl && refs.x >= 0, tr = hr && refs.y >= 0;
+                if (tl) {
+                    node = refs.x;
+                    if (tr) {
+                        if (sp < CPT_PW_STACK_LDS) my_nodes[sp * CPT_WAVE] = (uint32_t)refs.y;
+                        else my_spill[(size_t)(sp - CPT_PW_STACK_LDS) * spill_stride] = (uint32_t)refs.y;
+                        ++sp;
+                    }
+                } else if (tr) {
+                    node = refs.y;
+                } else if (sp > 0) {
+                    --sp;
+                    if (sp < CPT_PW_STACK_LDS) node = (int)my_nodes[sp * CPT_WAVE];
+                    else node = (int)my_spill[(size_t)(sp - CPT_PW_STACK_LDS) * spill_stride];
+                } else {
+                    node = -1;
                 }
-            } else if (tr) {
-                node = refs.y;
-            } else if (sp > 0) {
-                --sp;
-                if (sp < CPT_PW_STACK_LDS) node = (int)my_nodes[sp * CPT_WAVE];
-                else node = (int)my_spill[(size_t)(sp - CPT_PW_STACK_LDS) * spill_stride];
-            } else {
-                node = -1;
             }
         }
 
