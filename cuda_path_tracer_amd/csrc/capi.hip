@@ -296,6 +296,7 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
                 r.n[k] = t.n[k]; r.a[k] = t.a[k]; r.b[k] = t.b[k]; r.c[k] = t.c[k];
                 r.na[k] = tn.na[k]; r.nb[k] = tn.nb[k]; r.nc[k] = tn.nc[k];
                 r.ke[k] = m.ke[k]; r.kd[k] = m.kd[k]; r.ks[k] = m.ks[k]; r.kr[k] = m.kr[k]; r.kt[k] = m.kt[k];
+                r.log_kt[k] = std::log(m.kt[k]);  // -inf for kt = 0, NaN for kt < 0: the kernel then falls back to pow
             }
         }
         HIP_TRY(c, hipMemcpy(c->d_shade, recs.data(), sizeof(ShadeRec) * recs.size(), hipMemcpyHostToDevice));

@@ -21,7 +21,8 @@ struct __attribute__((aligned(128))) ShadeRec {
     double ks[3], kr[3], kt[3];        // second 128 bytes: specular / transmissive materials
     double a[3], b[3], c[3];           // vertices and vertex normals: smooth-shaded triangles only
     double na[3], nb[3], nc[3];
-    double pad1[5];
+    double log_kt[3];                  // log(kt), so that kt^t is one exp() at a hit inside the medium
+    double pad1[2];
 };
 static_assert(sizeof(ShadeRec) == 384, "ShadeRec is three 128-byte lines");
 
