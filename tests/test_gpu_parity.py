@@ -246,7 +246,7 @@ def test_edge_cases(gpu, host_scenes, oracle):
     # 1x1 image, depth 0, image sides that are not multiples of the 8x8 tile
     gpu.upload(host_scenes("cornell-box2"))
     orc = oracle.OracleScene(scene_path("cornell-box2"))
-    for (w, h, depth) in [(1, 1, 0), (9, 3, 1), (8, 8, 0)]:
+    for (w, h, depth) in [(1, 1, 0), (9, 3, 1), (8, 8, 0), (131, 2, 2), (8, 8, 100)]:  # ragged sides; far more bounces than any path survives
         acc = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
         gpu.render_into(acc.data_ptr(), gpu.params(w, h, 0, 3, depth))
         gpu.synchronize()
