@@ -8,8 +8,9 @@
 // Parity status: the reference itself cannot be built in this environment (it needs nvcc,
 // cuRAND, Thrust, and GLM 0.9.6 which its build fetches with git clone), and it ships no
 // known-answer tests.  The oracle is therefore pinned by (a) the reference's own scene files,
-// (b) the mean luminance of the reference's golden renders, and (c) the published Philox
-// known-answer vectors for the counter RNG.  Primary-ray hit ids / BVH visit sets are
+// (b) the mean luminance of the reference's golden renders (and, through the HIP path that is
+// compared with this restatement path by path, the 64 x 64 block means of all fifteen of them),
+// and (c) the published Philox known-answer vectors for the counter RNG.  Primary-ray hit ids / BVH visit sets are
 // "parity unpinned" against a running reference: they are pinned to this restatement.
 //
 // Arithmetic: IEEE-754 binary64, built with -ffp-contract=off, operations in the order the
