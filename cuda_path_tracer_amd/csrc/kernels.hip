@@ -160,6 +160,7 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
 #define CPT_PW_WAVES (CPT_PW_THREADS / CPT_WAVE)
 #define CPT_PW_CACHE_RECORDS 512  // 64 KB of 128-byte records
 #define CPT_PW_STACK_LDS 12
+static_assert(CPT_PW_CACHE_RECORDS == CPT_PW_CACHE_RECORDS_HOST, "record cache size must match the host's chunk choice");
 static_assert(CPT_PW_STACK_LDS == CPT_PW_STACK_LDS_HOST, "stack split must match the spill buffer sizing");
 #define CPT_PW_BOX_REPEAT 2   // node expansions per lane and loop turn
 #define CPT_PW_LEAF_CAP 10    // parked leaves per lane (a node expansion adds at most two)
@@ -227,6 +228,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     const size_t spill_stride = (size_t)gridDim.x * CPT_PW_THREADS;
     uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform: unclaimed part of this wave's chunk
     bool drained = false;                   // wave-uniform: the queue has been handed out completely
+    uint32_t seg = (blockIdx.x * CPT_PW_WAVES + wave) % CPT_PW_SEGMENTS, segs_empty = 0;  // wave-uniform: segment being claimed from
 
     bool has_ray = false;
     int node = -1, sp = 0, lp = 0;
@@ -242,13 +244,20 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
         // ---- refill idle lanes ----
         uint64_t idle = __ballot(!has_ray);
         if (!drained && (uint32_t)__popcll(idle) >= refill_at) {
-            if (chunk_pos == chunk_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor, chunk);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                chunk_pos = base < n ? base : n;
-                chunk_end = (base + chunk) < n ? (base + chunk) : n;
-                if (chunk_pos == chunk_end) drained = true;
+            while (chunk_pos == chunk_end && !drained) {  // claim the next chunk of this wave's current segment
+                const uint32_t seg_lo = (uint32_t)((uint64_t)n * seg / CPT_PW_SEGMENTS);
+                const uint32_t seg_hi = (uint32_t)((uint64_t)n * (seg + 1) / CPT_PW_SEGMENTS);
+                const uint32_t seg_size = seg_hi - seg_lo, size = chunk;
+                uint32_t off = 0;
+                if (lane == 0) off = atomicAdd(cursor + seg * 32u, size);
+                off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+                if (off < seg_size) {
+                    chunk_pos = seg_lo + off;
+                    chunk_end = (seg_size - off) < size ? seg_hi : chunk_pos + size;
+                } else {  // used up: on to the next segment; once all have been seen empty the stream is handed out
+                    seg = (seg + 1) % CPT_PW_SEGMENTS;
+                    if (++segs_empty == CPT_PW_SEGMENTS) drained = true;
+                }
             }
             uint32_t avail = chunk_end - chunk_pos;
             uint32_t want = (uint32_t)__popcll(idle);

@@ -88,6 +88,14 @@ struct Radiance {           // radiance gathered per path, indexed by slot; touc
 // traversal stack of the persistent-wave extend kernel: entries in LDS, and the deepest tree it accepts
 #define CPT_PW_STACK_LDS_HOST 12
 #define CPT_PW_STACK_MAX 62
+// The rays of a stream are handed to the persistent extend kernel's waves in small chunks.  One claim
+// counter for the whole stream would serialise the claims (an address takes on the order of 10^8
+// atomics per second), so the stream is cut into CPT_PW_SEGMENTS equal segments, each with a counter
+// of its own in its own 128-byte line; a wave works through its home segment and then helps with the
+// others.
+#define CPT_PW_SEGMENTS 16
+#define CPT_PW_CURSOR_WORDS (CPT_PW_SEGMENTS * 32)  // u32 words of claim counters per bounce
+#define CPT_PW_CACHE_RECORDS_HOST 512  // records of the scene the persistent extend kernel keeps in LDS
 #define CPT_PW_THREADS_HOST 1024
 
 struct LaunchCfg {

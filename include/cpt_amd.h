@@ -148,7 +148,8 @@ int cpt_set_stream(cpt_ctx* ctx, void* hip_stream);
  * "extend_variant" (1: persistent waves with an LDS record cache, default; 0: one ray per thread;
  * 2: as 1 but walking the nearer child first and skipping boxes entered beyond the closest hit so
  * far -- a fast mode that returns the same hits without reproducing the reference's visit set),
- * "pw_blocks" / "pw_chunk" (workgroups of the persistent extend kernel / rays claimed per atomic),
+ * "pw_blocks" / "pw_chunk" (workgroups of the persistent extend kernel / rays a wave claims per
+ * atomic, 0 = chosen from the scene size),
  * "pw_refill" / "pw_leaf_go" / "pw_full_go" (a wave of that kernel refills when this many lanes are
  * idle / runs its triangle pass when this many lanes have a parked leaf / or when this many lanes
  * cannot go on because their parked-leaf list is full). */
