@@ -31,7 +31,7 @@ struct cpt_ctx {
     void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr;
     DScene sc{};
     bool has_scene = false;
-    int n_tree_nodes = 0, tree_height = 0;
+    int n_tree_nodes = 0, tree_height = 0, measured_height = 0;
 
     // A lane is everything one batch of paths needs while it is in flight.  Consecutive batches of a
     // render go to alternating lanes, each on its own HIP stream, so that the arithmetic-bound extend
@@ -207,14 +207,19 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
 // scene that sits in the LDS record cache whole) want large chunks; a chunk is also what a wave may be
 // left holding when every other wave has run dry, so expensive rays want small ones.
 // Measured: 256 vs 64 is -9 % on the Cornell boxes and +30 % on the dragon.
+// Whether the persistent extend kernel can run without any global-memory record or stack traffic.
+static int scene_resident(const cpt_ctx* c) {
+    return c->has_scene && c->sc.n_nodes + c->sc.n_tris <= CPT_PW_CACHE_RECORDS_HOST && c->measured_height - 2 <= CPT_PW_STACK_LDS_HOST;
+}
+
 static int chunk_for(const cpt_ctx* c) {
     if (c->pw_chunk > 0) return c->pw_chunk;
-    return (c->has_scene && c->sc.n_nodes + c->sc.n_tris <= CPT_PW_CACHE_RECORDS_HOST) ? 256 : 64;
+    return scene_resident(c) ? 256 : 64;
 }
 
 // Structural validation of the flattened scene: every kernel indexes these arrays without bounds
 // checks, so a malformed scene must be refused here.
-static int validate_scene(cpt_ctx* c, const cpt_scene_desc* s) {
+static int validate_scene(cpt_ctx* c, const cpt_scene_desc* s, int* measured_height) {
     if (s->n_tris < 1) return fail(c, CPT_EINVAL, "scene has no triangles");
     if (s->n_materials < 1) return fail(c, CPT_EINVAL, "scene has no materials");
     if (!s->tris || !s->tri_normals || !s->materials) return fail(c, CPT_EINVAL, "scene arrays missing");
@@ -252,6 +257,7 @@ static int validate_scene(cpt_ctx* c, const cpt_scene_desc* s) {
             if (refs[q] >= 0) { level[(size_t)refs[q]] = level[(size_t)k] + 1; levels = std::max(levels, level[(size_t)k] + 1); }
     }
     const int height = levels + 1;  // plus the leaf level
+    *measured_height = height;
     if (height - 2 > CPT_STACK_ENTRIES_HOST || s->tree_height - 2 > CPT_STACK_ENTRIES_HOST)
         return fail(c, CPT_ELIMIT, "tree height %d needs a %d-entry stack; limit is %d", std::max(height, s->tree_height),
                     std::max(height, s->tree_height) - 2, CPT_STACK_ENTRIES_HOST);
@@ -260,7 +266,8 @@ static int validate_scene(cpt_ctx* c, const cpt_scene_desc* s) {
 
 int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     if (!c || !s) return CPT_EINVAL;
-    int rc = validate_scene(c, s);
+    int measured = 0;
+    int rc = validate_scene(c, s, &measured);
     if (rc != CPT_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -321,6 +328,7 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     c->sc.n_tris = s->n_tris;
     c->n_tree_nodes = s->n_tree_nodes;
     c->tree_height = s->tree_height;
+    c->measured_height = measured;
     c->has_scene = true;
     return CPT_OK;
 }
@@ -406,7 +414,7 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
     if (rc != CPT_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     if (P.s1 == P.s0) return CPT_OK;
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     unsigned long long* work = c->count_work ? c->d_work : nullptr;
     const bool timed = c->time_kernels;
     long long n_paths = (long long)P.w * P.h * (P.s1 - P.s0);
@@ -512,7 +520,7 @@ int cpt_tonemap(cpt_ctx* c, const double* d_accum, int32_t w, int32_t h, int32_t
     if (!c || !d_accum || !d_rgb) return c ? fail(c, CPT_EINVAL, "cpt_tonemap: NULL argument") : CPT_EINVAL;
     if (w < 1 || h < 1 || total_spp < 1) return fail(c, CPT_EINVAL, "cpt_tonemap: bad size or sample count");
     HIP_TRY(c, hipSetDevice(c->device));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     launch_tonemap(L, d_accum, w * h * 3, total_spp, d_rgb);
     HIP_TRY(c, hipGetLastError());
     return CPT_OK;
@@ -626,7 +634,7 @@ int cpt_trace_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, 
     if (h_bitmap) { HIP_TRY(c, bm.alloc(N * (size_t)stride)); HIP_TRY(c, hipMemsetAsync(bm.p, 0, N * (size_t)stride, c->stream)); }
     HIP_TRY(c, hipMemcpyAsync(o.p, h_o, N * 24, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d.p, h_d, N * 24, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     launch_trace_rays(L, c->sc, n, (const double*)o.p, (const double*)d.p, (int*)tri.p, (double*)t.p, (double*)nrm.p,
                       (unsigned long long*)vh.p, (int*)cnt.p, h_bitmap ? (uint8_t*)bm.p : nullptr, stride);
     HIP_TRY(c, hipGetLastError());
@@ -660,7 +668,7 @@ int cpt_extend_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d,
     uint32_t* cursors = ln.d_cursors;
     HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)ln.d_counters, n, 1, c->stream));
     HIP_TRY(c, hipMemsetAsync(cursors, 0, CPT_PW_CURSOR_WORDS * sizeof(uint32_t), c->stream));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     unsigned long long* work = c->count_work ? c->d_work : nullptr;
     if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, ln.d_counters, cursors, ln.d_spill, work);
     else launch_extend(L, c->sc, in, ln.H, ln.d_counters, (long long)n, work);
@@ -680,7 +688,7 @@ int cpt_camera_rays(cpt_ctx* c, int32_t w, int32_t h, double jx, double jy, doub
     size_t N = (size_t)w * h;
     DevBuf o, d;
     HIP_TRY(c, o.alloc(N * 24)); HIP_TRY(c, d.alloc(N * 24));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     launch_camera_rays(L, c->sc, w, h, jx, jy, (double*)o.p, (double*)d.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_o, o.p, N * 24, hipMemcpyDeviceToHost, c->stream));
@@ -704,7 +712,7 @@ int cpt_path_radiance(cpt_ctx* c, const cpt_render_params* p, int32_t n, const i
     size_t N = (size_t)n;
     HIP_TRY(c, ij.alloc(N * 12)); HIP_TRY(c, rad.alloc(N * 24));
     HIP_TRY(c, hipMemcpyAsync(ij.p, h_ijs, N * 12, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     launch_path_radiance(L, c->sc, P, n, (const int*)ij.p, (double*)rad.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_rad, rad.p, N * 24, hipMemcpyDeviceToHost, c->stream));
@@ -721,7 +729,7 @@ int cpt_probe_math(cpt_ctx* c, int32_t n, const double* h_a, const double* h_b, 
     HIP_TRY(c, a.alloc(N * 8)); HIP_TRY(c, b.alloc(N * 8)); HIP_TRY(c, s.alloc(N * 8)); HIP_TRY(c, q.alloc(N * 8));
     HIP_TRY(c, hipMemcpyAsync(a.p, h_a, N * 8, hipMemcpyHostToDevice, c->stream));
     if (h_b) HIP_TRY(c, hipMemcpyAsync(b.p, h_b, N * 8, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     launch_probe_math(L, n, (const double*)a.p, h_b ? (const double*)b.p : nullptr, (double*)s.p, (double*)q.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_sqrt, s.p, N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -735,7 +743,7 @@ int cpt_probe_rng(cpt_ctx* c, const uint32_t ctr[4], const uint32_t key[2], uint
     HIP_TRY(c, hipSetDevice(c->device));
     DevBuf o, u;
     HIP_TRY(c, o.alloc(16)); HIP_TRY(c, u.alloc(16));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     launch_probe_rng(L, ctr, key, (uint32_t*)o.p, (double*)u.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, o.p, 16, hipMemcpyDeviceToHost, c->stream));

@@ -175,10 +175,11 @@ __device__ __forceinline__ double2 lds_piece(const lds_byte* p) {
     v2d v = *(const lds_v2d*)p;
     return make_double2(v.x, v.y);
 }
+template <bool RESIDENT>
 __device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, const lds_byte* cache, int cache_first,
                                              int cached, int idx) {
     Rec7 r;
-    if (idx < cached) {
+    if (RESIDENT || idx < cached) {
         const uint32_t slot = (uint32_t)(cache_first + idx);
         const lds_byte* rec = cache + slot * 128u;
         const uint32_t z = (slot >> 1) & 7u;
@@ -198,7 +199,10 @@ __device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, cons
 // a box the ray enters beyond the closest hit found so far (with a relative margin of 1e-6) is not
 // walked at all.  The closest hit is the same one; the set of visited nodes, which the reference
 // mode reproduces exactly, is not.
-template <bool COUNT, bool CULL>
+// RESIDENT: the whole scene is in the record cache and its tree is low enough for the LDS part of the node
+// stack, so the loop has no vector-memory record or spill path and none of the waits that come with
+// them; the only loads left are the rays.
+template <bool COUNT, bool CULL, bool RESIDENT>
 __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStream in, HitBuf hit,
                                                               const uint32_t* __restrict__ counter, uint32_t* cursor,
                                                               uint32_t chunk, uint32_t refill_at, uint32_t leaf_go, uint32_t full_go, uint32_t* spill, unsigned long long* work) {
@@ -288,6 +292,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
             if (drained) break;
             continue;
         }
+    
 
         // ---- box phase: expand up to CPT_PW_BOX_REPEAT nodes per lane that has one (and room to park two more leaves) ----
         // (several expansions per turn of the loop spread its fixed costs -- ballots, refill and triangle-pass
@@ -299,7 +304,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 if (lane == 0 && boxing) box_passes++;
             }
             if (node >= 0 && lp <= CPT_PW_LEAF_CAP - 2) {
-                Rec7 r = fetch_record(sc.nodes, cache, 0, cached_nodes, node);
+                Rec7 r = fetch_record<RESIDENT>(sc.nodes, cache, 0, cached_nodes, node);
                 int2 refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));  // lref, rref
                 bool sure_l, sure_r;
                 double enter_l, enter_r;
@@ -327,7 +332,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 if (tl) {
                     node = refs.x;
                     if (tr) {
-                        if (sp < CPT_PW_STACK_LDS) my_nodes[sp * CPT_WAVE] = (uint32_t)refs.y;
+                        if (RESIDENT || sp < CPT_PW_STACK_LDS) my_nodes[sp * CPT_WAVE] = (uint32_t)refs.y;
                         else my_spill[(size_t)(sp - CPT_PW_STACK_LDS) * spill_stride] = (uint32_t)refs.y;
                         ++sp;
                     }
@@ -335,7 +340,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                     node = refs.y;
                 } else if (sp > 0) {
                     --sp;
-                    if (sp < CPT_PW_STACK_LDS) node = (int)my_nodes[sp * CPT_WAVE];
+                    if (RESIDENT || sp < CPT_PW_STACK_LDS) node = (int)my_nodes[sp * CPT_WAVE];
                     else node = (int)my_spill[(size_t)(sp - CPT_PW_STACK_LDS) * spill_stride];
                 } else {
                     node = -1;
@@ -353,7 +358,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 if (lp > 0) {
                     --lp;
                     int tri = (int)my_leaves[lp * CPT_WAVE];
-                    Rec7 q = fetch_record(sc.tris, cache, cached_nodes, cached_tris, tri);
+                    Rec7 q = fetch_record<RESIDENT>(sc.tris, cache, cached_nodes, cached_tris, tri);
                     uint32_t flags = (uint32_t)__double2hiint(q.p6.x), rank = (uint32_t)__double2loint(q.p6.y);
                     double t;
                     if (COUNT) tris++;
@@ -600,16 +605,21 @@ void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, co
 void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
                       uint32_t* cursor, uint32_t* spill, unsigned long long* work) {
     int g = L.pw_blocks;
-#define CPT_PW_LAUNCH(COUNT, CULL)                                                                                  \
-    hipLaunchKernelGGL((k_extend_pw<COUNT, CULL>), dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, \
-                       cursor, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go,                  \
+#define CPT_PW_LAUNCH(COUNT, CULL, RES)                                                                                  \
+    hipLaunchKernelGGL((k_extend_pw<COUNT, CULL, RES>), dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, \
+                       cursor, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go,                       \
                        (uint32_t)L.pw_full_go, spill, work)
-    if (L.pw_cull) {
-        if (work) CPT_PW_LAUNCH(true, true);
-        else CPT_PW_LAUNCH(false, true);
-    } else {
-        if (work) CPT_PW_LAUNCH(true, false);
-        else CPT_PW_LAUNCH(false, false);
+    const bool resident = L.pw_resident != 0;
+    const int which = (work ? 4 : 0) | (L.pw_cull ? 2 : 0) | (resident ? 1 : 0);
+    switch (which) {
+        case 0: CPT_PW_LAUNCH(false, false, false); break;
+        case 1: CPT_PW_LAUNCH(false, false, true); break;
+        case 2: CPT_PW_LAUNCH(false, true, false); break;
+        case 3: CPT_PW_LAUNCH(false, true, true); break;
+        case 4: CPT_PW_LAUNCH(true, false, false); break;
+        case 5: CPT_PW_LAUNCH(true, false, true); break;
+        case 6: CPT_PW_LAUNCH(true, true, false); break;
+        default: CPT_PW_LAUNCH(true, true, true); break;
     }
 #undef CPT_PW_LAUNCH
 }

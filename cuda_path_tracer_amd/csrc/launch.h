@@ -104,6 +104,7 @@ struct LaunchCfg {
     int pw_blocks;   // number of persistent 1024-thread workgroups of k_extend_pw (one per CU)
     int pw_chunk;    // queue entries a wave takes per atomic
     int pw_refill;   // a wave refills when at least this many of its lanes are idle
+    int pw_resident; // 1: scene fits the LDS record cache and its node stack fits the LDS entries (checked by the host)
     int pw_cull;     // 1: nearest-first walk with closest-hit culling (fast mode), 0: the reference's visit set
     int pw_full_go;  // ... or when at least this many lanes cannot expand a node because their parked-leaf list is full
     int pw_leaf_go;  // a wave runs its triangle phase when at least this many lanes have a parked leaf
