@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="batches in flight at once (library default when 0)")
+    ap.add_argument("--opt", action="append", default=[], help="key=value passed to cpt_set_option (tuning experiments)")
     args = ap.parse_args()
 
     import torch
@@ -139,6 +140,9 @@ def main():
             r.set_option("batch_paths", args.batch_paths)
         if args.streams:
             r.set_option("streams", args.streams)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            r.set_option(k, int(v))
         r.upload(hs)
         w = wl["width"]
         h = hs.height_for_width(w)

@@ -59,7 +59,7 @@ struct cpt_ctx {
     std::vector<hipEvent_t> events;
 
     int max_blocks = 0;            // grid cap of the grid-stride kernels
-    long long batch_paths = 1 << 23;  // path slots kept in flight by the wavefront pipeline
+    long long batch_paths = 1 << 26;  // path slots of one batch of the wavefront pipeline (8.3 GB of streams per batch in flight)
     int pw_blocks = 0;             // persistent workgroups of the extend kernel (one per CU)
     int pw_chunk = 0;              // rays a persistent wave claims per atomic; 0: chosen from the scene, see chunk_for
     int pw_refill = 12, pw_leaf_go = 32, pw_full_go = 1;
@@ -171,7 +171,7 @@ int cpt_set_instrumentation(cpt_ctx* c, int time_kernels, int count_work) {
 int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
     if (!c || !key) return CPT_EINVAL;
     if (!strcmp(key, "batch_paths")) {
-        if (value < 64) return fail(c, CPT_EINVAL, "batch_paths must be >= 64");
+        if (value < 64 || value > (1ll << 28)) return fail(c, CPT_EINVAL, "batch_paths must be in [64, 2^28]");
         c->batch_paths = value;
     } else if (!strcmp(key, "streams")) {
         if (value < 1 || value > CPT_MAX_LANES) return fail(c, CPT_EINVAL, "streams must be in [1, %d]", CPT_MAX_LANES);
