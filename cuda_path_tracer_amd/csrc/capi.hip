@@ -205,16 +205,11 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
 
 // Rays a wave claims at a time.  A claim stalls the wave for an atomic's round trip, so cheap rays (a
 // scene that sits in the LDS record cache whole) want large chunks; a chunk is also what a wave may be
-// left holding when every other wave has run dry, so expensive rays want small ones.
-// Measured: 256 vs 64 is -9 % on the Cornell boxes and +30 % on the dragon.
-// Whether the persistent extend kernel can run without any global-memory record or stack traffic.
-static int scene_resident(const cpt_ctx* c) {
-    return c->has_scene && c->sc.n_nodes + c->sc.n_tris <= CPT_PW_CACHE_RECORDS_HOST && c->measured_height - 2 <= CPT_PW_STACK_LDS_HOST;
-}
-
+// left holding when every other wave has run dry, so expensive rays want smaller ones.
+// Measured on the dragon: 8 M-ray launches 64 beats 256 by 30 %, 64 M-ray launches 128 beats 64 by 2 %.
 static int chunk_for(const cpt_ctx* c) {
     if (c->pw_chunk > 0) return c->pw_chunk;
-    return scene_resident(c) ? 256 : 64;
+    return scene_resident(c) ? 256 : 128;
 }
 
 // Structural validation of the flattened scene: every kernel indexes these arrays without bounds
