@@ -203,6 +203,11 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
     return CPT_OK;
 }
 
+// Whether the persistent extend kernel can run without any global-memory record or stack traffic.
+static int scene_resident(const cpt_ctx* c) {
+    return c->has_scene && c->sc.n_nodes + c->sc.n_tris <= CPT_PW_CACHE_RECORDS_HOST && c->measured_height - 2 <= CPT_PW_STACK_LDS_HOST;
+}
+
 // Rays a wave claims at a time.  A claim stalls the wave for an atomic's round trip, so cheap rays (a
 // scene that sits in the LDS record cache whole) want large chunks; a chunk is also what a wave may be
 // left holding when every other wave has run dry, so expensive rays want smaller ones.
