@@ -212,6 +212,12 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     const uint32_t lane = threadIdx.x & (CPT_WAVE - 1), wave = threadIdx.x / CPT_WAVE;
     const uint64_t lanes_below = (1ull << lane) - 1ull;
     const uint32_t n = *counter;
+    // A wave's last chunk is the tail of the launch (its lanes finish one by one while the other waves have
+    // nothing left), so a short stream is handed out in smaller chunks: at least eight claims per wave.
+    {
+        const uint32_t fair = n / (gridDim.x * CPT_PW_WAVES * 8u);
+        chunk = fair < chunk ? (fair < 32u ? 32u : fair) : chunk;
+    }
 
     // fill the record cache: node records first, triangle records in what is left
     const int cached_nodes = sc.n_nodes < CPT_PW_CACHE_RECORDS ? sc.n_nodes : CPT_PW_CACHE_RECORDS;
