@@ -23,18 +23,22 @@
     __shared__ uint32_t s_stack[CPT_WAVES_PER_BLOCK][CPT_STACK_ENTRIES][CPT_WAVE];          \
     uint32_t* my_stack = &s_stack[threadIdx.x / CPT_WAVE][0][threadIdx.x % CPT_WAVE];
 
+// Streams are written once and read once, each time by another kernel: non-temporal accesses keep them from
+// displacing the scene records in L2.
+#define CPT_NT_LOAD(p) __builtin_nontemporal_load(&(p))
+#define CPT_NT_STORE(p, v) __builtin_nontemporal_store((v), &(p))
 __device__ __forceinline__ void load_ray(const RayStream& R, uint32_t p, PathRegs& s) {
-    s.o = dv(R.ox[p], R.oy[p], R.oz[p]);
-    s.d = dv(R.dx[p], R.dy[p], R.dz[p]);
-    s.medium = R.medium[p];
-    s.atten = dv(R.ax[p], R.ay[p], R.az[p]);
+    s.o = dv(CPT_NT_LOAD(R.ox[p]), CPT_NT_LOAD(R.oy[p]), CPT_NT_LOAD(R.oz[p]));
+    s.d = dv(CPT_NT_LOAD(R.dx[p]), CPT_NT_LOAD(R.dy[p]), CPT_NT_LOAD(R.dz[p]));
+    s.medium = CPT_NT_LOAD(R.medium[p]);
+    s.atten = dv(CPT_NT_LOAD(R.ax[p]), CPT_NT_LOAD(R.ay[p]), CPT_NT_LOAD(R.az[p]));
 }
 __device__ __forceinline__ void store_ray(const RayStream& R, uint32_t p, const PathRegs& s, uint32_t slot) {
-    R.ox[p] = s.o.x; R.oy[p] = s.o.y; R.oz[p] = s.o.z;
-    R.dx[p] = s.d.x; R.dy[p] = s.d.y; R.dz[p] = s.d.z;
-    R.medium[p] = s.medium;
-    R.ax[p] = s.atten.x; R.ay[p] = s.atten.y; R.az[p] = s.atten.z;
-    R.slot[p] = slot;
+    CPT_NT_STORE(R.ox[p], s.o.x); CPT_NT_STORE(R.oy[p], s.o.y); CPT_NT_STORE(R.oz[p], s.o.z);
+    CPT_NT_STORE(R.dx[p], s.d.x); CPT_NT_STORE(R.dy[p], s.d.y); CPT_NT_STORE(R.dz[p], s.d.z);
+    CPT_NT_STORE(R.medium[p], s.medium);
+    CPT_NT_STORE(R.ax[p], s.atten.x); CPT_NT_STORE(R.ay[p], s.atten.y); CPT_NT_STORE(R.az[p], s.atten.z);
+    CPT_NT_STORE(R.slot[p], slot);
 }
 
 // Compaction: positions in the output stream for the threads of a workgroup that keep their path,
@@ -98,11 +102,11 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_generate(DScene sc, DParams P, Ra
             atten = dv(0, 0, 0);
         }
         const uint32_t p = (uint32_t)slot;
-        out.ox[p] = o.x; out.oy[p] = o.y; out.oz[p] = o.z;
-        out.dx[p] = d.x; out.dy[p] = d.y; out.dz[p] = d.z;
-        out.medium[p] = 1.0;
-        out.ax[p] = atten.x; out.ay[p] = atten.y; out.az[p] = atten.z;
-        out.slot[p] = p;
+        CPT_NT_STORE(out.ox[p], o.x); CPT_NT_STORE(out.oy[p], o.y); CPT_NT_STORE(out.oz[p], o.z);
+        CPT_NT_STORE(out.dx[p], d.x); CPT_NT_STORE(out.dy[p], d.y); CPT_NT_STORE(out.dz[p], d.z);
+        CPT_NT_STORE(out.medium[p], 1.0);
+        CPT_NT_STORE(out.ax[p], atten.x); CPT_NT_STORE(out.ay[p], atten.y); CPT_NT_STORE(out.az[p], atten.z);
+        CPT_NT_STORE(out.slot[p], p);
         col.cx[slot] = 0.0; col.cy[slot] = 0.0; col.cz[slot] = 0.0;
     }
 }
@@ -275,8 +279,8 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
             uint32_t mine = (uint32_t)__popcll(idle & lanes_below);
             if (!has_ray && mine < take) {
                 pos = chunk_pos + mine;  // idle lanes take consecutive positions: one contiguous run per refill
-                o = dv(in.ox[pos], in.oy[pos], in.oz[pos]);
-                d = dv(in.dx[pos], in.dy[pos], in.dz[pos]);
+                o = dv(CPT_NT_LOAD(in.ox[pos]), CPT_NT_LOAD(in.oy[pos]), CPT_NT_LOAD(in.oz[pos]));
+                d = dv(CPT_NT_LOAD(in.dx[pos]), CPT_NT_LOAD(in.dy[pos]), CPT_NT_LOAD(in.dz[pos]));
                 sr = slab_prepare(o, d);
                 best_t = -1.0;
                 best_tri = -1;
@@ -377,8 +381,8 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
 
         // ---- retire ----
         if (has_ray && node < 0 && lp == 0) {
-            hit.t[pos] = best_t;
-            hit.tri[pos] = best_tri;
+            CPT_NT_STORE(hit.t[pos], best_t);
+            CPT_NT_STORE(hit.tri[pos], best_tri);
             has_ray = false;
         }
     }
@@ -406,16 +410,16 @@ __global__ void __launch_bounds__(CPT_SHADE_BLOCK, 4) k_shade(DScene sc, DParams
         uint32_t slot = 0;
         PathRegs s;
         if (q < n) {
-            int tri = hit.tri[q];
+            int tri = CPT_NT_LOAD(hit.tri[q]);
             if (COUNT) { segs++; hits += (tri >= 0); }
             if (tri >= 0) {
-                slot = in.slot[q];
+                slot = CPT_NT_LOAD(in.slot[q]);
                 int k = (int)slot / P.n_pix_slots, ps = (int)slot - k * P.n_pix_slots;
                 int i, j;
                 slot_to_pixel(P, ps, i, j);
                 uint32_t pixel = (uint32_t)(i + j * P.w), sample = (uint32_t)(batch_s0 + k);
                 load_ray(in, q, s);
-                double t = hit.t[q];
+                double t = CPT_NT_LOAD(hit.t[q]);
                 dvec3 emitted;
                 int lobe = choose_lobe(sc, P, pixel, sample, bounce, tri, s.atten, emitted);
                 if (emitted.x != 0.0 || emitted.y != 0.0 || emitted.z != 0.0) {  // adding zero changes nothing: skip the round trip
