@@ -341,9 +341,8 @@ static int ensure_paths(cpt_ctx* c, cpt_ctx::Lane& l, hipStream_t st, size_t slo
     HIP_TRY(c, hipMalloc(&l.d_paths, slots * CPT_SLOT_BYTES));
     double* p = (double*)l.d_paths;
     for (int b = 0; b < 2; ++b) {
-        double** f[CPT_STREAM_DOUBLES] = {&l.R[b].ox, &l.R[b].oy, &l.R[b].oz, &l.R[b].dx, &l.R[b].dy, &l.R[b].dz,
-                                          &l.R[b].medium, &l.R[b].ax, &l.R[b].ay, &l.R[b].az};
-        for (int k = 0; k < CPT_STREAM_DOUBLES; ++k) { *f[k] = p; p += slots; }
+        cpt_v2d** f[CPT_STREAM_DOUBLES / 2] = {&l.R[b].oxy, &l.R[b].ozdx, &l.R[b].dyz, &l.R[b].mdax, &l.R[b].ayz};
+        for (int k = 0; k < CPT_STREAM_DOUBLES / 2; ++k) { *f[k] = (cpt_v2d*)p; p += 2 * slots; }
     }
     l.H.t = p; p += slots;
     l.C.cx = p; p += slots;
@@ -659,12 +658,14 @@ int cpt_extend_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d,
     rc = ensure_paths(c, ln, c->stream, (size_t)n);
     if (rc) return rc;
     const size_t N = (size_t)n;
-    std::vector<double> soa(6 * N);  // the stream is structure-of-arrays by position
-    for (size_t i = 0; i < N; ++i)
-        for (int k = 0; k < 3; ++k) { soa[(size_t)k * N + i] = h_o[3 * i + k]; soa[(size_t)(3 + k) * N + i] = h_d[3 * i + k]; }
+    std::vector<double> packed(6 * N);  // the stream keeps components in pairs: (ox, oy) | (oz, dx) | (dy, dz)
+    for (size_t i = 0; i < N; ++i) {
+        const double v[6] = {h_o[3 * i], h_o[3 * i + 1], h_o[3 * i + 2], h_d[3 * i], h_d[3 * i + 1], h_d[3 * i + 2]};
+        for (int k = 0; k < 3; ++k) { packed[(size_t)k * 2 * N + 2 * i] = v[2 * k]; packed[(size_t)k * 2 * N + 2 * i + 1] = v[2 * k + 1]; }
+    }
     const RayStream& in = ln.R[0];
-    double* dst[6] = {in.ox, in.oy, in.oz, in.dx, in.dy, in.dz};
-    for (int k = 0; k < 6; ++k) HIP_TRY(c, hipMemcpyAsync(dst[k], soa.data() + (size_t)k * N, N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    cpt_v2d* dst[3] = {in.oxy, in.ozdx, in.dyz};
+    for (int k = 0; k < 3; ++k) HIP_TRY(c, hipMemcpyAsync(dst[k], packed.data() + (size_t)k * 2 * N, 2 * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     uint32_t* cursors = ln.d_cursors;
     HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)ln.d_counters, n, 1, c->stream));
     HIP_TRY(c, hipMemsetAsync(cursors, 0, CPT_PW_CURSOR_WORDS * sizeof(uint32_t), c->stream));

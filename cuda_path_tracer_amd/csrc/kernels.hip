@@ -27,18 +27,29 @@
 // displacing the scene records in L2.
 #define CPT_NT_LOAD(p) __builtin_nontemporal_load(&(p))
 #define CPT_NT_STORE(p, v) __builtin_nontemporal_store((v), &(p))
+__device__ __forceinline__ void load_ray_geometry(const RayStream& R, uint32_t p, dvec3& o, dvec3& d) {
+    const cpt_v2d a = CPT_NT_LOAD(R.oxy[p]), b = CPT_NT_LOAD(R.ozdx[p]), c = CPT_NT_LOAD(R.dyz[p]);
+    o = dv(a.x, a.y, b.x);
+    d = dv(b.y, c.x, c.y);
+}
 __device__ __forceinline__ void load_ray(const RayStream& R, uint32_t p, PathRegs& s) {
-    s.o = dv(CPT_NT_LOAD(R.ox[p]), CPT_NT_LOAD(R.oy[p]), CPT_NT_LOAD(R.oz[p]));
-    s.d = dv(CPT_NT_LOAD(R.dx[p]), CPT_NT_LOAD(R.dy[p]), CPT_NT_LOAD(R.dz[p]));
-    s.medium = CPT_NT_LOAD(R.medium[p]);
-    s.atten = dv(CPT_NT_LOAD(R.ax[p]), CPT_NT_LOAD(R.ay[p]), CPT_NT_LOAD(R.az[p]));
+    load_ray_geometry(R, p, s.o, s.d);
+    const cpt_v2d m = CPT_NT_LOAD(R.mdax[p]), a = CPT_NT_LOAD(R.ayz[p]);
+    s.medium = m.x;
+    s.atten = dv(m.y, a.x, a.y);
+}
+__device__ __forceinline__ void store_ray(const RayStream& R, uint32_t p, const dvec3& o, const dvec3& d, double medium,
+                                          const dvec3& atten, uint32_t slot) {
+    cpt_v2d v;
+    v.x = o.x; v.y = o.y; CPT_NT_STORE(R.oxy[p], v);
+    v.x = o.z; v.y = d.x; CPT_NT_STORE(R.ozdx[p], v);
+    v.x = d.y; v.y = d.z; CPT_NT_STORE(R.dyz[p], v);
+    v.x = medium; v.y = atten.x; CPT_NT_STORE(R.mdax[p], v);
+    v.x = atten.y; v.y = atten.z; CPT_NT_STORE(R.ayz[p], v);
+    CPT_NT_STORE(R.slot[p], slot);
 }
 __device__ __forceinline__ void store_ray(const RayStream& R, uint32_t p, const PathRegs& s, uint32_t slot) {
-    CPT_NT_STORE(R.ox[p], s.o.x); CPT_NT_STORE(R.oy[p], s.o.y); CPT_NT_STORE(R.oz[p], s.o.z);
-    CPT_NT_STORE(R.dx[p], s.d.x); CPT_NT_STORE(R.dy[p], s.d.y); CPT_NT_STORE(R.dz[p], s.d.z);
-    CPT_NT_STORE(R.medium[p], s.medium);
-    CPT_NT_STORE(R.ax[p], s.atten.x); CPT_NT_STORE(R.ay[p], s.atten.y); CPT_NT_STORE(R.az[p], s.atten.z);
-    CPT_NT_STORE(R.slot[p], slot);
+    store_ray(R, p, s.o, s.d, s.medium, s.atten, slot);
 }
 
 // Compaction: positions in the output stream for the threads of a workgroup that keep their path,
@@ -102,11 +113,7 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_generate(DScene sc, DParams P, Ra
             atten = dv(0, 0, 0);
         }
         const uint32_t p = (uint32_t)slot;
-        CPT_NT_STORE(out.ox[p], o.x); CPT_NT_STORE(out.oy[p], o.y); CPT_NT_STORE(out.oz[p], o.z);
-        CPT_NT_STORE(out.dx[p], d.x); CPT_NT_STORE(out.dy[p], d.y); CPT_NT_STORE(out.dz[p], d.z);
-        CPT_NT_STORE(out.medium[p], 1.0);
-        CPT_NT_STORE(out.ax[p], atten.x); CPT_NT_STORE(out.ay[p], atten.y); CPT_NT_STORE(out.az[p], atten.z);
-        CPT_NT_STORE(out.slot[p], p);
+        store_ray(out, p, o, d, 1.0, atten, p);
         col.cx[slot] = 0.0; col.cy[slot] = 0.0; col.cz[slot] = 0.0;
     }
 }
@@ -121,8 +128,8 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
     uint32_t n = *counter;
     unsigned long long steps = 0, tris = 0;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
-        dvec3 o = dv(in.ox[q], in.oy[q], in.oz[q]);
-        dvec3 d = dv(in.dx[q], in.dy[q], in.dz[q]);
+        dvec3 o, d;
+        load_ray_geometry(in, q, o, d);
         double t;
         int tri;
         if (COUNT) {
@@ -279,8 +286,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
             uint32_t mine = (uint32_t)__popcll(idle & lanes_below);
             if (!has_ray && mine < take) {
                 pos = chunk_pos + mine;  // idle lanes take consecutive positions: one contiguous run per refill
-                o = dv(CPT_NT_LOAD(in.ox[pos]), CPT_NT_LOAD(in.oy[pos]), CPT_NT_LOAD(in.oz[pos]));
-                d = dv(CPT_NT_LOAD(in.dx[pos]), CPT_NT_LOAD(in.dy[pos]), CPT_NT_LOAD(in.dz[pos]));
+                load_ray_geometry(in, pos, o, d);
                 sr = slab_prepare(o, d);
                 best_t = -1.0;
                 best_tri = -1;

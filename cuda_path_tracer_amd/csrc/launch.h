@@ -67,12 +67,13 @@ struct DParams {  // cpt_render_params plus what the kernels derive from it
 // position p and writes the hit for p, shade reads p and writes the surviving paths, compacted, at
 // consecutive positions of the other stream.  Nothing is gathered through an index; every access
 // is a contiguous run per wave.  `slot` says which path (pixel slot and sample) a position holds.
+// Components are stored in pairs so that every access is a 16-byte load or store per lane (half the
+// memory instructions of one array per component).
+typedef double cpt_v2d __attribute__((ext_vector_type(2)));
 struct RayStream {
-    double *ox, *oy, *oz;   // ray origin
-    double *dx, *dy, *dz;   // ray direction
-    double* medium;         // refractive index of the current medium
-    double *ax, *ay, *az;   // throughput
-    uint32_t* slot;         // path slot = k * n_pix_slots + pixel slot
+    cpt_v2d *oxy, *ozdx, *dyz;  // ray origin x,y | origin z, direction x | direction y,z: all extend reads
+    cpt_v2d *mdax, *ayz;        // refractive index of the current medium, throughput x | throughput y,z
+    uint32_t* slot;             // path slot = k * n_pix_slots + pixel slot
 };
 #define CPT_STREAM_DOUBLES 10
 #define CPT_STREAM_BYTES (CPT_STREAM_DOUBLES * 8 + 4)
