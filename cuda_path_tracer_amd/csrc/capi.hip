@@ -344,14 +344,13 @@ static int ensure_paths(cpt_ctx* c, cpt_ctx::Lane& l, hipStream_t st, size_t slo
         cpt_v2d** f[CPT_STREAM_DOUBLES / 2] = {&l.R[b].oxy, &l.R[b].ozdx, &l.R[b].dyz, &l.R[b].mdax, &l.R[b].ayz};
         for (int k = 0; k < CPT_STREAM_DOUBLES / 2; ++k) { *f[k] = (cpt_v2d*)p; p += 2 * slots; }
     }
-    l.H.t = p; p += slots;
+    l.H.rec = (HitRec*)p; p += 2 * slots;
     l.C.cx = p; p += slots;
     l.C.cy = p; p += slots;
     l.C.cz = p; p += slots;
     uint32_t* u = (uint32_t*)p;
     l.R[0].slot = u; u += slots;
     l.R[1].slot = u; u += slots;
-    l.H.tri = (int*)u;
     l.path_capacity = slots;
     return CPT_OK;
 }
@@ -675,9 +674,10 @@ int cpt_extend_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d,
     else launch_extend(L, c->sc, in, ln.H, ln.d_counters, (long long)n, work);
     HIP_TRY(c, hipGetLastError());
     c->stats.launches_extend++;
-    HIP_TRY(c, hipMemcpyAsync(h_t, ln.H.t, N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(h_tri, ln.H.tri, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    std::vector<HitRec> recs(N);
+    HIP_TRY(c, hipMemcpyAsync(recs.data(), ln.H.rec, N * sizeof(HitRec), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < N; ++i) { h_t[i] = recs[i].t; h_tri[i] = recs[i].tri; }
     if (work) return collect_work(c);
     return CPT_OK;
 }

@@ -52,6 +52,18 @@ __device__ __forceinline__ void store_ray(const RayStream& R, uint32_t p, const 
     store_ray(R, p, s.o, s.d, s.medium, s.atten, slot);
 }
 
+__device__ __forceinline__ void store_hit(const HitBuf& H, uint32_t p, double t, int tri) {
+    cpt_v2d v;
+    v.x = t;
+    v.y = __hiloint2double(0, tri);
+    CPT_NT_STORE(((cpt_v2d*)H.rec)[p], v);
+}
+__device__ __forceinline__ void load_hit(const HitBuf& H, uint32_t p, double& t, int& tri) {
+    const cpt_v2d v = CPT_NT_LOAD(((const cpt_v2d*)H.rec)[p]);
+    t = v.x;
+    tri = __double2loint(v.y);
+}
+
 // Compaction: positions in the output stream for the threads of a workgroup that keep their path,
 // in thread order, behind one atomic.  A single queue counter takes on the order of 10^8 atomics
 // per second however many CUs issue them; at one atomic per wave that limit, not the shading, set
@@ -140,8 +152,7 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
         } else {
             traverse<false>(sc, o, d, my_stack, t, tri, nullptr);
         }
-        hit.t[q] = t;
-        hit.tri[q] = tri;
+        store_hit(hit, q, t, tri);
     }
     if (COUNT) {
         if (steps) atomicAdd(&work[3], steps);
@@ -387,8 +398,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
 
         // ---- retire ----
         if (has_ray && node < 0 && lp == 0) {
-            CPT_NT_STORE(hit.t[pos], best_t);
-            CPT_NT_STORE(hit.tri[pos], best_tri);
+            store_hit(hit, pos, best_t, best_tri);
             has_ray = false;
         }
     }
@@ -416,7 +426,9 @@ __global__ void __launch_bounds__(CPT_SHADE_BLOCK, 4) k_shade(DScene sc, DParams
         uint32_t slot = 0;
         PathRegs s;
         if (q < n) {
-            int tri = CPT_NT_LOAD(hit.tri[q]);
+            int tri;
+            double t;
+            load_hit(hit, q, t, tri);
             if (COUNT) { segs++; hits += (tri >= 0); }
             if (tri >= 0) {
                 slot = CPT_NT_LOAD(in.slot[q]);
@@ -425,7 +437,6 @@ __global__ void __launch_bounds__(CPT_SHADE_BLOCK, 4) k_shade(DScene sc, DParams
                 slot_to_pixel(P, ps, i, j);
                 uint32_t pixel = (uint32_t)(i + j * P.w), sample = (uint32_t)(batch_s0 + k);
                 load_ray(in, q, s);
-                double t = CPT_NT_LOAD(hit.t[q]);
                 dvec3 emitted;
                 int lobe = choose_lobe(sc, P, pixel, sample, bounce, tri, s.atten, emitted);
                 if (emitted.x != 0.0 || emitted.y != 0.0 || emitted.z != 0.0) {  // adding zero changes nothing: skip the round trip

@@ -77,14 +77,18 @@ struct RayStream {
 };
 #define CPT_STREAM_DOUBLES 10
 #define CPT_STREAM_BYTES (CPT_STREAM_DOUBLES * 8 + 4)
+struct HitRec {             // 16 bytes: one store in extend, one load in shade
+    double t;               // hit distance (meaningful when tri >= 0)
+    int32_t tri;            // triangle index or -1
+    int32_t pad_;
+};
 struct HitBuf {             // extend -> shade, indexed by queue position
-    double* t;
-    int* tri;
+    HitRec* rec;
 };
 struct Radiance {           // radiance gathered per path, indexed by slot; touched only at emitters
     double *cx, *cy, *cz;
 };
-#define CPT_SLOT_BYTES (2 * CPT_STREAM_BYTES + 12 + 24)  // device bytes per path slot of a batch
+#define CPT_SLOT_BYTES (2 * CPT_STREAM_BYTES + 16 + 24)  // device bytes per path slot of a batch: two streams, hit record, radiance
 
 // traversal stack of the persistent-wave extend kernel: entries in LDS, and the deepest tree it accepts
 #define CPT_PW_STACK_LDS_HOST 12
