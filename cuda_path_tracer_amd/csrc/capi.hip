@@ -219,15 +219,21 @@ static int chunk_for(const cpt_ctx* c) {
 
 // Structural validation of the flattened scene: every kernel indexes these arrays without bounds
 // checks, so a malformed scene must be refused here.
-static int validate_scene(cpt_ctx* c, const cpt_scene_desc* s, int* measured_height) {
+static int validate_triangles(cpt_ctx* c, const cpt_scene_desc* s) {
     if (s->n_tris < 1) return fail(c, CPT_EINVAL, "scene has no triangles");
     if (s->n_materials < 1) return fail(c, CPT_EINVAL, "scene has no materials");
     if (!s->tris || !s->tri_normals || !s->materials) return fail(c, CPT_EINVAL, "scene arrays missing");
+    for (int i = 0; i < s->n_tris; ++i)
+        if (s->tris[i].material < 0 || s->tris[i].material >= s->n_materials) return fail(c, CPT_EINVAL, "triangle %d: bad material", i);
+    return CPT_OK;
+}
+
+static int validate_scene(cpt_ctx* c, const cpt_scene_desc* s, int* measured_height) {
+    int rc = validate_triangles(c, s);
+    if (rc != CPT_OK) return rc;
     if (s->n_nodes != s->n_tris - 1) return fail(c, CPT_EINVAL, "n_nodes (%d) != n_tris - 1 (%d)", s->n_nodes, s->n_tris - 1);
     if (s->n_nodes > 0 && !s->nodes) return fail(c, CPT_EINVAL, "nodes missing");
     if (s->n_tree_nodes != 2 * s->n_tris - 1) return fail(c, CPT_EINVAL, "n_tree_nodes must be 2*n_tris-1");
-    for (int i = 0; i < s->n_tris; ++i)
-        if (s->tris[i].material < 0 || s->tris[i].material >= s->n_materials) return fail(c, CPT_EINVAL, "triangle %d: bad material", i);
     std::vector<unsigned char> seen_tri((size_t)s->n_tris, 0), seen_node((size_t)std::max(s->n_nodes, 1), 0);
     for (int k = 0; k < s->n_nodes; ++k) {
         for (int q = 0; q < 6; ++q)  // the division-free box test assumes finite planes
@@ -261,6 +267,31 @@ static int validate_scene(cpt_ctx* c, const cpt_scene_desc* s, int* measured_hei
     if (height - 2 > CPT_STACK_ENTRIES_HOST || s->tree_height - 2 > CPT_STACK_ENTRIES_HOST)
         return fail(c, CPT_ELIMIT, "tree height %d needs a %d-entry stack; limit is %d", std::max(height, s->tree_height),
                     std::max(height, s->tree_height) - 2, CPT_STACK_ENTRIES_HOST);
+    return CPT_OK;
+}
+
+// One shading record per triangle: geometry, vertex normals and a copy of its material.
+static int upload_shading(cpt_ctx* c, const cpt_scene_desc* s) {
+    std::vector<ShadeRec> recs((size_t)s->n_tris);
+    for (int i = 0; i < s->n_tris; ++i) {
+        const cpt_tri& t = s->tris[i];
+        const cpt_tri_normals& tn = s->tri_normals[i];
+        const cpt_material& m = s->materials[t.material];
+        ShadeRec& r = recs[(size_t)i];
+        memset(&r, 0, sizeof r);
+        r.tri_flags = t.flags;
+        r.mat_flags = m.flags;
+        const LobeProb pr = lobe_probabilities(m.kd, m.ks, m.kt);
+        r.p_diff = pr.diff; r.p_spec = pr.spec; r.p_trans = pr.trans;
+        r.index = m.index;
+        for (int k = 0; k < 3; ++k) {
+            r.n[k] = t.n[k]; r.a[k] = t.a[k]; r.b[k] = t.b[k]; r.c[k] = t.c[k];
+            r.na[k] = tn.na[k]; r.nb[k] = tn.nb[k]; r.nc[k] = tn.nc[k];
+            r.ke[k] = m.ke[k]; r.kd[k] = m.kd[k]; r.ks[k] = m.ks[k]; r.kr[k] = m.kr[k]; r.kt[k] = m.kt[k];
+            r.log_kt[k] = std::log(m.kt[k]);  // -inf for kt = 0, NaN for kt < 0: the kernel then falls back to pow
+        }
+    }
+    HIP_TRY(c, hipMemcpy(c->d_shade, recs.data(), sizeof(ShadeRec) * recs.size(), hipMemcpyHostToDevice));
     return CPT_OK;
 }
 
@@ -298,28 +329,8 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
         }
         HIP_TRY(c, hipMemcpy(c->d_tris, tris.data(), sizeof(cpt_tri) * (size_t)s->n_tris, hipMemcpyHostToDevice));
     }
-    {   // one shading record per triangle: geometry, vertex normals and a copy of its material
-        std::vector<ShadeRec> recs((size_t)s->n_tris);
-        for (int i = 0; i < s->n_tris; ++i) {
-            const cpt_tri& t = s->tris[i];
-            const cpt_tri_normals& tn = s->tri_normals[i];
-            const cpt_material& m = s->materials[t.material];
-            ShadeRec& r = recs[(size_t)i];
-            memset(&r, 0, sizeof r);
-            r.tri_flags = t.flags;
-            r.mat_flags = m.flags;
-            const LobeProb pr = lobe_probabilities(m.kd, m.ks, m.kt);
-            r.p_diff = pr.diff; r.p_spec = pr.spec; r.p_trans = pr.trans;
-            r.index = m.index;
-            for (int k = 0; k < 3; ++k) {
-                r.n[k] = t.n[k]; r.a[k] = t.a[k]; r.b[k] = t.b[k]; r.c[k] = t.c[k];
-                r.na[k] = tn.na[k]; r.nb[k] = tn.nb[k]; r.nc[k] = tn.nc[k];
-                r.ke[k] = m.ke[k]; r.kd[k] = m.kd[k]; r.ks[k] = m.ks[k]; r.kr[k] = m.kr[k]; r.kt[k] = m.kt[k];
-                r.log_kt[k] = std::log(m.kt[k]);  // -inf for kt = 0, NaN for kt < 0: the kernel then falls back to pow
-            }
-        }
-        HIP_TRY(c, hipMemcpy(c->d_shade, recs.data(), sizeof(ShadeRec) * recs.size(), hipMemcpyHostToDevice));
-    }
+    rc = upload_shading(c, s);
+    if (rc != CPT_OK) return rc;
     c->sc.nodes = (const cpt_node*)c->d_nodes;
     c->sc.tris = (const cpt_tri*)c->d_tris;
     c->sc.shade = (const ShadeRec*)c->d_shade;
@@ -330,6 +341,82 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     c->tree_height = s->tree_height;
     c->measured_height = measured;
     c->has_scene = true;
+    return CPT_OK;
+}
+
+// Height limits shared by every traversal kernel: the per-lane LDS stack of the hooks and the per-pixel kernel.
+#define CPT_MAX_TREE_HEIGHT (CPT_STACK_ENTRIES_HOST + 2)
+
+int cpt_build_scene(cpt_ctx* c, const cpt_scene_desc* s) {
+    if (!c || !s) return CPT_EINVAL;
+    int rc = validate_triangles(c, s);
+    if (rc != CPT_OK) return rc;
+    for (int i = 0; i < s->n_tris; ++i)  // Morton codes and box unions need finite vertices
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(s->tris[i].a[k]) || !std::isfinite(s->tris[i].b[k]) || !std::isfinite(s->tris[i].c[k]))
+                return fail(c, CPT_EINVAL, "triangle %d: vertex is not finite", i);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    const int n = s->n_tris;
+    HIP_TRY(c, hipMalloc(&c->d_nodes, sizeof(cpt_node) * (size_t)std::max(n - 1, 1)));
+    HIP_TRY(c, hipMalloc(&c->d_tris, sizeof(cpt_tri) * (size_t)n));
+    HIP_TRY(c, hipMalloc(&c->d_shade, sizeof(ShadeRec) * (size_t)n));
+    {
+        std::vector<cpt_tri> tris(s->tris, s->tris + n);
+        for (cpt_tri& t : tris) t.test_rank = 0;
+        HIP_TRY(c, hipMemcpy(c->d_tris, tris.data(), sizeof(cpt_tri) * (size_t)n, hipMemcpyHostToDevice));
+    }
+    rc = upload_shading(c, s);
+    if (rc != CPT_OK) return rc;
+    int height = 1;
+    if (n >= 2) {
+        void* work = nullptr;
+        HIP_TRY(c, hipMalloc(&work, lbvh_work_bytes(n)));
+        // Ten Morton bits per axis first; a tree too tall for the traversal stacks (long runs of nearly
+        // coincident triangles) is rebuilt with coarser codes, which trade depth for balance: with no Morton bits
+        // at all the tree is the balanced one over the input order.
+        hipError_t e = hipSuccess;
+        for (int bits = 10; bits >= 0; bits -= 2) {
+            e = launch_lbvh_build(c->stream, (cpt_tri*)c->d_tris, n, (cpt_node*)c->d_nodes, work, bits, &height);
+            if (e != hipSuccess || height <= CPT_MAX_TREE_HEIGHT) break;
+        }
+        (void)hipFree(work);
+        if (e != hipSuccess) return fail(c, CPT_EHIP, "device BVH build: %s", hipGetErrorString(e));
+        if (height > CPT_MAX_TREE_HEIGHT)
+            return fail(c, CPT_ELIMIT, "tree height %d needs a %d-entry stack; limit is %d", height, height - 2, CPT_STACK_ENTRIES_HOST);
+    }
+    c->sc.nodes = (const cpt_node*)c->d_nodes;
+    c->sc.tris = (const cpt_tri*)c->d_tris;
+    c->sc.shade = (const ShadeRec*)c->d_shade;
+    c->sc.cam = s->camera;
+    c->sc.n_nodes = n - 1;
+    c->sc.n_tris = n;
+    c->n_tree_nodes = 2 * n - 1;
+    c->tree_height = height;
+    c->measured_height = height;
+    c->has_scene = true;
+    return CPT_OK;
+}
+
+int cpt_download_tree(cpt_ctx* c, cpt_node* h_nodes, int32_t node_capacity, uint32_t* h_test_rank, int32_t tri_capacity,
+                      int32_t* n_nodes, int32_t* height) {
+    if (!c) return CPT_EINVAL;
+    if (!c->has_scene) return fail(c, CPT_ENOSCENE, "no scene uploaded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_nodes) *n_nodes = c->sc.n_nodes;
+    if (height) *height = c->measured_height;
+    if (h_nodes) {
+        if (node_capacity < c->sc.n_nodes) return fail(c, CPT_EINVAL, "node buffer holds %d records, the tree has %d", node_capacity, c->sc.n_nodes);
+        if (c->sc.n_nodes > 0)
+            HIP_TRY(c, hipMemcpy(h_nodes, c->d_nodes, sizeof(cpt_node) * (size_t)c->sc.n_nodes, hipMemcpyDeviceToHost));
+    }
+    if (h_test_rank) {
+        if (tri_capacity < c->sc.n_tris) return fail(c, CPT_EINVAL, "rank buffer holds %d entries, the scene has %d triangles", tri_capacity, c->sc.n_tris);
+        std::vector<cpt_tri> tris((size_t)c->sc.n_tris);
+        HIP_TRY(c, hipMemcpy(tris.data(), c->d_tris, sizeof(cpt_tri) * tris.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tris.size(); ++i) h_test_rank[i] = tris[i].test_rank;
+    }
     return CPT_OK;
 }
 

@@ -133,3 +133,8 @@ void launch_camera_rays(const LaunchCfg& L, const DScene& sc, int w, int h, doub
 void launch_path_radiance(const LaunchCfg& L, const DScene& sc, const DParams& P, int n, const int* ijs, double* rad);
 void launch_probe_math(const LaunchCfg& L, int n, const double* a, const double* b, double* s, double* q);
 void launch_probe_rng(const LaunchCfg& L, const uint32_t c[4], const uint32_t k[2], uint32_t* out, double* out_u);
+
+// Device-side BVH construction (bvh_device.hip).
+size_t lbvh_work_bytes(int n_tris);
+hipError_t launch_lbvh_build(hipStream_t st, cpt_tri* d_tris, int n_tris, cpt_node* d_nodes, void* d_work, int morton_bits,
+                             int* h_height);

@@ -15,6 +15,11 @@ class CptError(RuntimeError):
     pass
 
 
+NODE_DTYPE = np.dtype([("lbox", np.float64, 6), ("rbox", np.float64, 6), ("lref", np.int32), ("rref", np.int32),
+                       ("lid", np.int32), ("rid", np.int32), ("self_id", np.int32), ("pad_", np.int32, 3)])
+assert NODE_DTYPE.itemsize == C.sizeof(_capi.Node)
+
+
 def _vp(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
@@ -66,6 +71,21 @@ class Renderer:
     def upload(self, host_scene):
         self._check(self._L.cpt_upload_scene(self._h, C.byref(host_scene.desc)), "cpt_upload_scene")
         self._scene = host_scene  # keeps the host arrays alive, and n_tree_nodes for bitmaps
+
+    def build(self, host_scene):
+        """Upload triangles, materials and camera and build the BVH on the GPU (the host scene's own tree is not used)."""
+        self._check(self._L.cpt_build_scene(self._h, C.byref(host_scene.desc)), "cpt_build_scene")
+        self._scene = host_scene
+
+    def download_tree(self):
+        """(nodes, test_rank, height) of the scene on the GPU: node records as a structured array of _capi.Node."""
+        n, h = C.c_int32(0), C.c_int32(0)
+        self._check(self._L.cpt_download_tree(self._h, None, 0, None, 0, C.byref(n), C.byref(h)), "cpt_download_tree")
+        nodes = np.zeros(max(n.value, 1), dtype=NODE_DTYPE)
+        rank = np.zeros(self._scene.desc.n_tris, np.uint32)
+        self._check(self._L.cpt_download_tree(self._h, _vp(nodes), nodes.shape[0], _vp(rank), rank.shape[0], C.byref(n), C.byref(h)),
+                    "cpt_download_tree")
+        return nodes[:n.value], rank, h.value
 
     @staticmethod
     def params(width, height, sample_begin, sample_end, depth, mode=MODE_WAVEFRONT, seed=1984, dof=False,

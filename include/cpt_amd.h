@@ -162,6 +162,21 @@ int cpt_set_instrumentation(cpt_ctx* ctx, int time_kernels, int count_work);
  * (reference: src/path_tracer.cu:519-520, src/gpu/GPUScene.cuh:25-57, src/gpu/GPUBVH.cu:9-31). */
 int cpt_upload_scene(cpt_ctx* ctx, const cpt_scene_desc* scene);
 
+/* Copy the triangles, normals, materials and camera of `scene` to the GPU and build the BVH there
+ * (`scene->nodes`, `n_nodes`, `n_tree_nodes` and `tree_height` are ignored).  Replaces the host build
+ * `BVHTree::build` (reference: src/scene/bvh.cpp:101-220) together with the upload above, for callers
+ * that do not need the reference's tree: the result is a Morton-order tree with exact boxes, so renders
+ * are statistically the same image but visit sets, step counts and the winner among equal-t hits are
+ * this tree's own.  A tree too tall for the traversal stacks is rebuilt with coarser Morton codes;
+ * CPT_ELIMIT if even that fails.  Synchronous. */
+int cpt_build_scene(cpt_ctx* ctx, const cpt_scene_desc* scene);
+
+/* Read back the node records (and, if h_test_rank is not NULL, every triangle's tie-break rank) of the
+ * scene on the GPU, however it got there.  h_nodes may be NULL to query *n_nodes / *height only.
+ * No reference counterpart: lets a host inspect, cache or cross-check a device-built tree. */
+int cpt_download_tree(cpt_ctx* ctx, cpt_node* h_nodes, int32_t node_capacity, uint32_t* h_test_rank, int32_t tri_capacity,
+                      int32_t* n_nodes, int32_t* height);
+
 /* ---- rendering -------------------------------------------------------------------------- */
 
 /* Add the radiance of samples [sample_begin, sample_end) of every pixel to d_accum

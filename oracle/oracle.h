@@ -99,6 +99,7 @@ struct Scene {
 
 Scene* load_scene(const std::string& path, std::string& err);
 void build_bvh(Scene& s);
+bool replace_tree(Scene& s, int n, const double* boxes, const int* topo);
 
 // --- GPU-semantics traversal (src/gpu/GPUBVH.cu:38-99) --------------------------------------
 struct TraceOut {

@@ -72,6 +72,9 @@ void orc_get_nodes(void* h, double* boxes, int* topo) {
     }
 }
 
+// Swap in a tree built elsewhere (same table format as orc_get_nodes, row 0 = root); 1 on success.
+int orc_set_tree(void* h, int n, const double* boxes, const int* topo) { return replace_tree(*(Scene*)h, n, boxes, topo) ? 1 : 0; }
+
 // eye, look, u, v (12 doubles)
 void orc_get_camera(void* h, double* out12) {
     Scene* s = (Scene*)h;

@@ -411,4 +411,39 @@ void build_bvh(Scene& s) {
     s.height = number_preorder(s, s.root);
 }
 
+// Replaces the scene's tree by one given as a table (row 0 = root): boxes n*6 (min, max), topo n*3
+// (left row, right row, prim; -1 for none).  The traversal under test (GPUBVH.cu:38-99) is defined for any
+// binary tree, so this lets the checker walk a tree that some other builder produced.  Returns false if the
+// table is not a tree over this scene's triangles.
+bool replace_tree(Scene& s, int n, const double* boxes, const int* topo) {
+    if (n != 2 * (int)s.prims.size() - 1) return false;
+    std::vector<Node*> rows((size_t)n);
+    for (int i = 0; i < n; ++i) rows[(size_t)i] = new Node();
+    std::vector<int> parents((size_t)n, 0), used((size_t)s.prims.size(), 0);
+    bool ok = true;
+    for (int i = 0; i < n && ok; ++i) {
+        Node* nd = rows[(size_t)i];
+        nd->bmin = V3{boxes[6 * i], boxes[6 * i + 1], boxes[6 * i + 2]};
+        nd->bmax = V3{boxes[6 * i + 3], boxes[6 * i + 4], boxes[6 * i + 5]};
+        int l = topo[3 * i], r = topo[3 * i + 1], p = topo[3 * i + 2];
+        if (p >= 0) {
+            ok = l < 0 && r < 0 && p < (int)s.prims.size() && !used[(size_t)p]++;
+            nd->prim = p;
+        } else {
+            ok = l > 0 && r > 0 && l < n && r < n && l != r && !parents[(size_t)l]++ && !parents[(size_t)r]++;
+            if (ok) { nd->left = rows[(size_t)l]; nd->right = rows[(size_t)r]; }
+        }
+    }
+    for (int i = 1; i < n && ok; ++i) ok = parents[(size_t)i] == 1;
+    if (!ok) {
+        for (Node* nd : rows) delete nd;
+        return false;
+    }
+    for (Node* nd : s.nodes) delete nd;
+    s.nodes.clear();
+    s.root = rows[0];
+    s.height = number_preorder(s, s.root);
+    return true;
+}
+
 }  // namespace orc

@@ -46,8 +46,11 @@ class OracleScene:
         self._h = L.orc_load(os.fsencode(path), err, 512)
         if not self._h:
             raise RuntimeError("oracle: %s: %s" % (path, err.value.decode()))
+        self._refresh_counts()
+
+    def _refresh_counts(self):
         c = np.zeros(4, np.int32)
-        L.orc_counts(C.c_void_p(self._h), _p(c))
+        lib().orc_counts(C.c_void_p(self._h), _p(c))
         self.n_prims, self.n_nodes, self.n_meshes, self.height = (int(x) for x in c)
 
     def close(self):
@@ -83,6 +86,14 @@ class OracleScene:
         topo = np.zeros((self.n_nodes, 3), np.int32)
         lib().orc_get_nodes(self.h, _p(boxes), _p(topo))
         return boxes, topo
+
+    def set_tree(self, boxes, topo):
+        """Replace the tree by a table in the format of nodes() (row 0 = root); node ids become its preorder."""
+        boxes = np.ascontiguousarray(boxes, np.float64)
+        topo = np.ascontiguousarray(topo, np.int32)
+        if not lib().orc_set_tree(self.h, C.c_int(boxes.shape[0]), _p(boxes), _p(topo)):
+            raise ValueError("not a binary tree over this scene's triangles")
+        self._refresh_counts()
 
     def camera(self):
         c = np.zeros(12, np.float64)

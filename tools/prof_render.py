@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--stats", action="store_true", help="time kernels with HIP events and count work")
     ap.add_argument("--count", action="store_true", help="one extra render with work counters on")
+    ap.add_argument("--device-build", action="store_true", help="build the BVH on the GPU instead of uploading the host tree")
     ap.add_argument("--opt", action="append", default=[], help="key=value passed to cpt_set_option")
     args = ap.parse_args()
     import torch
@@ -31,7 +32,21 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         r.set_option(k, int(v))
-    r.upload(hs)
+    t0 = time.perf_counter()
+    hs2 = HostScene(os.path.join(ROOT, "tests", "golden", "scenes", args.scene + ".ray"))
+    t_host = time.perf_counter() - t0
+    del hs2
+    for rep in range(3):
+        t0 = time.perf_counter()
+        if args.device_build:
+            r.build(hs)
+        else:
+            r.upload(hs)
+        r.synchronize()
+        t_up = time.perf_counter() - t0
+    print("%s: %d triangles; host parse+build+flatten %.1f ms; %s %.2f ms; tree height %d" %
+          (args.scene, hs.n_tris, t_host * 1e3, "device build (upload, build, sync)" if args.device_build else "upload of host tree",
+           t_up * 1e3, r.download_tree()[2]), flush=True)
     w = args.width
     h = hs.height_for_width(w)
     acc = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
