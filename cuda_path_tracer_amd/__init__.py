@@ -10,4 +10,4 @@ libraries works, using it raises.
 """
 from ._capi import MODE_MEGAKERNEL, MODE_WAVEFRONT, BuildMissing  # noqa: F401
 from .render import CptError, Renderer  # noqa: F401
-from .scene import HostScene, write_image  # noqa: F401
+from .scene import ArrayScene, HostScene, write_image  # noqa: F401

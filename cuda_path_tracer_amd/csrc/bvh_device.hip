@@ -13,11 +13,17 @@
 //   k_morton            key = morton(centre) << 32 | triangle
 //   k_radix_*           stable LSD radix sort on the Morton bits, 8 bits a pass
 //   k_hierarchy         Karras' range/split search: children, parents, first leaf of every node
-//   k_fit               bottom-up: each leaf climbs, the second arrival at a node joins the two boxes
 //   k_number            preorder numbers, depth and expansion order of every node by walking up
 //   k_radix_* (1 pass)  nodes into level order (a prefix of the record array is the top of the tree,
 //                       which is what the extend kernel keeps in LDS)
-//   k_emit              final records with renumbered child references; tie-break ranks of triangles
+//   k_level_starts      where each level begins in that order
+//   k_fit_level         one launch per level, deepest first: a node's record = its children's boxes (a
+//                       leaf's bounds, or the union of the two boxes in the child's finished record),
+//                       renumbered child references and ids.  The usual single-launch bottom-up pass
+//                       (second thread to arrive at a node carries on) needs a device-scope release and
+//                       acquire per node, which on this chip means L2 write-backs and invalidations
+//                       across eight L2s; kernel boundaries give the same ordering for a few launches
+//   k_ranks             tie-break ranks of the triangles
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -54,13 +60,22 @@ __global__ void k_centroid_bounds(const cpt_tri* __restrict__ tris, int n, unsig
     __shared__ unsigned long long s[6];
     if (threadIdx.x < 6) s[threadIdx.x] = threadIdx.x < 3 ? ~0ull : 0ull;
     __syncthreads();
+    unsigned long long lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0ull, 0ull, 0ull};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         Box b = tri_box(tris[i]);
         for (int k = 0; k < 3; ++k) {
             unsigned long long c = ordered(0.5 * (b.lo[k] + b.hi[k]));
-            atomicMin(&s[k], c);
-            atomicMax(&s[3 + k], c);
+            lo[k] = c < lo[k] ? c : lo[k];
+            hi[k] = c > hi[k] ? c : hi[k];
         }
+    }
+    for (int k = 0; k < 3; ++k) {
+        for (int off = 32; off >= 1; off >>= 1) {
+            unsigned long long a = __shfl_xor(lo[k], off), c = __shfl_xor(hi[k], off);
+            lo[k] = a < lo[k] ? a : lo[k];
+            hi[k] = c > hi[k] ? c : hi[k];
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s[k], lo[k]); atomicMax(&s[3 + k], hi[k]); }
     }
     __syncthreads();
     if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], s[threadIdx.x]);
@@ -116,29 +131,82 @@ __global__ void __launch_bounds__(64) k_radix_hist(const unsigned long long* __r
     for (int d = threadIdx.x; d < 256; d += 64) hist[(size_t)d * n_tiles + blockIdx.x] = s[d];
 }
 
-// Exclusive scan of `count` words by one workgroup of 1024 threads.
+// Exclusive scan of `count` words by one workgroup of 1024 threads: every thread sums a contiguous run, the
+// 1024 sums are scanned through LDS (wave scans by lane shuffles, then the 16 wave totals), and every thread
+// walks its run again writing prefixes.
 __global__ void __launch_bounds__(1024) k_radix_scan(uint32_t* __restrict__ v, int count) {
-    __shared__ uint32_t s_part[1024];
-    __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
+    __shared__ uint32_t s_wave[16];
+    const int run = (count + 1023) / 1024;
+    const int begin = (int)threadIdx.x * run;
+    const int end = begin + run < count ? begin + run : count;
+    uint32_t sum = 0;
+    for (int i = begin; i < end; ++i) sum += v[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(incl, off);
+        if (lane >= off) incl += y;
+    }
+    if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    for (int base = 0; base < count; base += 1024) {
-        int i = base + (int)threadIdx.x;
-        uint32_t x = i < count ? v[i] : 0u;
-        s_part[threadIdx.x] = x;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-            uint32_t y = threadIdx.x >= (unsigned)off ? s_part[threadIdx.x - off] : 0u;
-            __syncthreads();
-            s_part[threadIdx.x] += y;
-            __syncthreads();
-        }
-        uint32_t incl = s_part[threadIdx.x];
-        uint32_t carry = s_carry;
-        if (i < count) v[i] = carry + incl - x;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + incl;
-        __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += s_wave[w];
+    uint32_t prefix = base + incl - sum;
+    for (int i = begin; i < end; ++i) {
+        uint32_t x = v[i];
+        v[i] = prefix;
+        prefix += x;
+    }
+}
+
+// Scan of a long array in three steps: sums of 4096-word blocks, the scan above over those sums, then each
+// block scans its own words (four per thread, wave scans by lane shuffles) on top of its block's prefix.
+#define LB_SCAN_BLOCK 4096
+
+__device__ inline uint4 load4_guarded(const uint32_t* __restrict__ v, int i, int count) {
+    uint4 x = {0u, 0u, 0u, 0u};
+    if (i + 3 < count) return *(const uint4*)(v + i);
+    if (i < count) x.x = v[i];
+    if (i + 1 < count) x.y = v[i + 1];
+    if (i + 2 < count) x.z = v[i + 2];
+    return x;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_block_sums(const uint32_t* __restrict__ v, int count, uint32_t* __restrict__ sums) {
+    __shared__ uint32_t s_wave[16];
+    uint4 x = load4_guarded(v, blockIdx.x * LB_SCAN_BLOCK + (int)threadIdx.x * 4, count);
+    uint32_t sum = x.x + x.y + x.z + x.w;
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 16; ++w) t += s_wave[w];
+        sums[blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_scan_apply(uint32_t* __restrict__ v, int count, const uint32_t* __restrict__ block_prefix) {
+    __shared__ uint32_t s_wave[16];
+    const int i = blockIdx.x * LB_SCAN_BLOCK + (int)threadIdx.x * 4;
+    uint4 x = load4_guarded(v, i, count);
+    const uint32_t sum = x.x + x.y + x.z + x.w;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(incl, off);
+        if (lane >= off) incl += y;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t p = block_prefix[blockIdx.x] + incl - sum;
+    for (int w = 0; w < wave; ++w) p += s_wave[w];
+    uint4 out = {p, p + x.x, p + x.x + x.y, p + x.x + x.y + x.z};
+    if (i + 3 < count) *(uint4*)(v + i) = out;
+    else {
+        if (i < count) v[i] = out.x;
+        if (i + 1 < count) v[i + 1] = out.y;
+        if (i + 2 < count) v[i + 2] = out.z;
     }
 }
 
@@ -214,36 +282,6 @@ __global__ void k_hierarchy(const unsigned long long* __restrict__ keys, int n, 
     if (i == 0) parent_int[0] = -1;
 }
 
-// ---- boxes ----------------------------------------------------------------------------------------------
-
-// One thread per leaf.  A thread writes its box into its parent's record and bumps the parent's arrival
-// counter; the first to arrive stops, the second (which then sees both boxes: the counter is an
-// acquire-release operation at device scope) joins them and carries the result one level up.
-__global__ void k_fit(const cpt_tri* __restrict__ tris, const unsigned long long* __restrict__ keys, int n,
-                      const int* __restrict__ right, const int* __restrict__ parent_int, const int* __restrict__ parent_leaf,
-                      uint32_t* __restrict__ arrived, cpt_node* __restrict__ work) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    Box b = tri_box(tris[(uint32_t)keys[p]]);
-    int node = parent_leaf[p];
-    bool from_right = right[node] == ~p;
-    for (;;) {
-        double* dst = from_right ? work[node].rbox : work[node].lbox;
-        for (int k = 0; k < 3; ++k) { dst[k] = b.lo[k]; dst[3 + k] = b.hi[k]; }
-        uint32_t before = __hip_atomic_fetch_add(&arrived[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (before == 0u) return;
-        if (node == 0) return;  // the root's own box is never tested
-        const double* other = from_right ? work[node].lbox : work[node].rbox;
-        for (int k = 0; k < 3; ++k) {
-            b.lo[k] = fmin(b.lo[k], other[k]);
-            b.hi[k] = fmax(b.hi[k], other[3 + k]);
-        }
-        int up = parent_int[node];
-        from_right = right[up] == node;
-        node = up;
-    }
-}
-
 // ---- numbering --------------------------------------------------------------------------------------------
 
 // For a node whose first leaf is at sorted position l, with `depth` ancestors of which `turns` were
@@ -284,41 +322,71 @@ __global__ void k_number(int n, const int* __restrict__ right, const int* __rest
     }
 }
 
-__global__ void k_new_index(const unsigned long long* __restrict__ level_keys, int m, int* __restrict__ new_index) {
+// level_sorted: internal nodes sorted by depth (key = depth << 32 | node).  new_index[node] = position in
+// that order = final record index; level_start[d] = first position of depth d, level_start[max depth + 1] = m.
+__global__ void k_level_starts(const unsigned long long* __restrict__ level_sorted, int m, int* __restrict__ new_index,
+                               int* __restrict__ level_start) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) new_index[(uint32_t)level_keys[i]] = i;
+    if (i >= m) return;
+    unsigned long long key = level_sorted[i];
+    new_index[(uint32_t)key] = i;
+    int d = (int)(key >> 32);
+    if (i == 0 || (int)(level_sorted[i - 1] >> 32) != d) level_start[d] = i;
+    if (i == m - 1) level_start[d + 1] = m;
 }
 
-__global__ void k_emit(const unsigned long long* __restrict__ keys, int n, const int* __restrict__ left, const int* __restrict__ right,
-                       const int* __restrict__ parent_leaf, const int* __restrict__ node_id, const int* __restrict__ node_order,
-                       const int* __restrict__ leaf_id, const int* __restrict__ new_index, const cpt_node* __restrict__ work,
-                       cpt_node* __restrict__ nodes, cpt_tri* __restrict__ tris) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int m = n - 1;
-    if (i < m) {
-        cpt_node r = work[i];
-        int lr = left[i], rr = right[i];
-        r.lref = lr >= 0 ? new_index[lr] : ~(int)(uint32_t)keys[~lr];
-        r.rref = rr >= 0 ? new_index[rr] : ~(int)(uint32_t)keys[~rr];
-        r.lid = lr >= 0 ? node_id[lr] : leaf_id[~lr];
-        r.rid = rr >= 0 ? node_id[rr] : leaf_id[~rr];
-        r.self_id = node_id[i];
+// Final records of one level.  Children are one level deeper or leaves, so their records are complete.
+__global__ void k_fit_level(const unsigned long long* __restrict__ level_sorted, const int* __restrict__ level_start, int level,
+                            const unsigned long long* __restrict__ keys, const cpt_tri* __restrict__ tris,
+                            const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ node_id,
+                            const int* __restrict__ leaf_id, const int* __restrict__ new_index, cpt_node* __restrict__ nodes) {
+    const int begin = level_start[level], end = level_start[level + 1];
+    for (int i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
+        const int node = (int)(uint32_t)level_sorted[i];
+        cpt_node r;
+        const int refs[2] = {left[node], right[node]};
+        int out_ref[2], out_id[2];
+        for (int side = 0; side < 2; ++side) {
+            double* dst = side ? r.rbox : r.lbox;
+            const int ref = refs[side];
+            if (ref < 0) {
+                const int tri = (int)(uint32_t)keys[~ref];
+                Box b = tri_box(tris[tri]);
+                for (int k = 0; k < 3; ++k) { dst[k] = b.lo[k]; dst[3 + k] = b.hi[k]; }
+                out_ref[side] = ~tri;
+                out_id[side] = leaf_id[~ref];
+            } else {
+                const cpt_node& c = nodes[new_index[ref]];
+                for (int k = 0; k < 3; ++k) {
+                    dst[k] = fmin(c.lbox[k], c.rbox[k]);
+                    dst[3 + k] = fmax(c.lbox[3 + k], c.rbox[3 + k]);
+                }
+                out_ref[side] = new_index[ref];
+                out_id[side] = node_id[ref];
+            }
+        }
+        r.lref = out_ref[0]; r.rref = out_ref[1];
+        r.lid = out_id[0]; r.rid = out_id[1];
+        r.self_id = node_id[node];
         r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
-        nodes[new_index[i]] = r;
-    } else if (i < m + n) {
-        int p = i - m;
-        int up = parent_leaf[p];
-        tris[(uint32_t)keys[p]].test_rank = 2u * (uint32_t)node_order[up] + (right[up] == ~p ? 1u : 0u);
+        nodes[i] = r;
     }
+}
+
+__global__ void k_ranks(const unsigned long long* __restrict__ keys, int n, const int* __restrict__ right,
+                        const int* __restrict__ parent_leaf, const int* __restrict__ node_order, cpt_tri* __restrict__ tris) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int up = parent_leaf[p];
+    tris[(uint32_t)keys[p]].test_rank = 2u * (uint32_t)node_order[up] + (right[up] == ~p ? 1u : 0u);
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Work {
     unsigned long long *keys_a, *keys_b, *keys_c, *bounds;
-    uint32_t *hist, *arrived, *max_depth;
-    int *left, *right, *parent_int, *parent_leaf, *first, *node_id, *node_order, *leaf_id, *new_index;
-    cpt_node* recs;
+    uint32_t *hist, *max_depth;
+    int *left, *right, *parent_int, *parent_leaf, *first, *node_id, *node_order, *leaf_id, *new_index, *level_start;
     size_t bytes;
 };
 
@@ -331,12 +399,11 @@ Work carve(char* base, int n) {
     w.keys_b = (unsigned long long*)take(8 * (size_t)n);
     w.keys_c = (unsigned long long*)take(8 * (size_t)n);
     w.bounds = (unsigned long long*)take(8 * 6);
-    w.hist = (uint32_t*)take(4 * 256 * tiles);
-    w.arrived = (uint32_t*)take(4 * (size_t)n);
+    w.hist = (uint32_t*)take(4 * (256 * tiles + (256 * tiles + LB_SCAN_BLOCK - 1) / LB_SCAN_BLOCK + 4));
     w.max_depth = (uint32_t*)take(4);
     int** ints[] = {&w.left, &w.right, &w.parent_int, &w.parent_leaf, &w.first, &w.node_id, &w.node_order, &w.leaf_id, &w.new_index};
     for (int** q : ints) *q = (int*)take(4 * (size_t)n);
-    w.recs = (cpt_node*)take(sizeof(cpt_node) * (size_t)n);
+    w.level_start = (int*)take(4 * 258);
     w.bytes = off;
     return w;
 }
@@ -344,11 +411,42 @@ Work carve(char* base, int n) {
 void radix_pass(hipStream_t st, const unsigned long long* in, unsigned long long* out, int n, int shift, uint32_t* hist) {
     int tiles = (n + LB_SORT_TILE - 1) / LB_SORT_TILE;
     k_radix_hist<<<tiles, 64, 0, st>>>(in, n, shift, hist, tiles);
-    k_radix_scan<<<1, 1024, 0, st>>>(hist, 256 * tiles);
+    const int count = 256 * tiles;
+    if (count <= 4 * LB_SCAN_BLOCK) {
+        k_radix_scan<<<1, 1024, 0, st>>>(hist, count);
+    } else {
+        const int blocks = (count + LB_SCAN_BLOCK - 1) / LB_SCAN_BLOCK;
+        uint32_t* sums = hist + count;  // room for it is part of the histogram allocation
+        k_scan_block_sums<<<blocks, 1024, 0, st>>>(hist, count, sums);
+        k_radix_scan<<<1, 1024, 0, st>>>(sums, blocks);
+        k_scan_apply<<<blocks, 1024, 0, st>>>(hist, count, sums);
+    }
     k_radix_scatter<<<tiles, 64, 0, st>>>(in, out, n, shift, hist, tiles);
 }
 
 }  // namespace
+
+// Shading records: the material's record (filled on the host, one per material) with the triangle's own
+// geometry and vertex normals put in.  One thread per triangle.
+__global__ void k_build_shade(const cpt_tri* __restrict__ tris, const cpt_tri_normals* __restrict__ normals,
+                              const ShadeRec* __restrict__ by_material, int n, ShadeRec* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const cpt_tri& t = tris[i];
+    const cpt_tri_normals& tn = normals[i];
+    ShadeRec r = by_material[t.material];
+    r.tri_flags = t.flags;
+    for (int k = 0; k < 3; ++k) {
+        r.n[k] = t.n[k]; r.a[k] = t.a[k]; r.b[k] = t.b[k]; r.c[k] = t.c[k];
+        r.na[k] = tn.na[k]; r.nb[k] = tn.nb[k]; r.nc[k] = tn.nc[k];
+    }
+    out[i] = r;
+}
+
+void launch_build_shade(hipStream_t st, const cpt_tri* d_tris, const cpt_tri_normals* d_normals, const ShadeRec* d_by_material,
+                        int n_tris, ShadeRec* d_out) {
+    k_build_shade<<<(n_tris + LB_THREADS - 1) / LB_THREADS, LB_THREADS, 0, st>>>(d_tris, d_normals, d_by_material, n_tris, d_out);
+}
 
 size_t lbvh_work_bytes(int n_tris) { return carve(nullptr, n_tris).bytes; }
 
@@ -362,9 +460,8 @@ hipError_t launch_lbvh_build(hipStream_t st, cpt_tri* d_tris, int n_tris, cpt_no
     hipError_t e;
     if ((e = hipMemsetAsync(w.bounds, 0xff, 8 * 3, st)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(w.bounds + 3, 0, 8 * 3, st)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(w.arrived, 0, 4 * (size_t)n, st)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(w.max_depth, 0, 4, st)) != hipSuccess) return e;
-    const int gn = (n + LB_THREADS - 1) / LB_THREADS, gall = (n + m + LB_THREADS - 1) / LB_THREADS;
+    const int gn = (n + LB_THREADS - 1) / LB_THREADS, gm = (m + LB_THREADS - 1) / LB_THREADS, gall = (n + m + LB_THREADS - 1) / LB_THREADS;
     k_centroid_bounds<<<gn < 1024 ? gn : 1024, LB_THREADS, 0, st>>>(d_tris, n, w.bounds);
     k_morton<<<gn, LB_THREADS, 0, st>>>(d_tris, n, w.bounds, morton_bits, w.keys_a);
     unsigned long long *src = w.keys_a, *dst = w.keys_b;
@@ -374,21 +471,28 @@ hipError_t launch_lbvh_build(hipStream_t st, cpt_tri* d_tris, int n_tris, cpt_no
     }
     // src: sorted keys; dst: free, reused for the level keys
     k_hierarchy<<<gn, LB_THREADS, 0, st>>>(src, n, w.left, w.right, w.parent_int, w.parent_leaf, w.first);
-    k_fit<<<gn, LB_THREADS, 0, st>>>(d_tris, src, n, w.right, w.parent_int, w.parent_leaf, w.arrived, w.recs);
     k_number<<<gall, LB_THREADS, 0, st>>>(n, w.right, w.parent_int, w.parent_leaf, w.first, w.node_id, w.node_order, w.leaf_id, dst,
                                           w.max_depth);
     // Level order: the keys are listed in expansion order, and one stable pass on the depth (< 256) keeps that
     // order inside a level.  Children are deeper than their parents, so they come after them.
-    if (m > 0) {
-        radix_pass(st, dst, w.keys_c, m, 32, w.hist);
-        k_new_index<<<(m + LB_THREADS - 1) / LB_THREADS, LB_THREADS, 0, st>>>(w.keys_c, m, w.new_index);
-    }
-    k_emit<<<gall, LB_THREADS, 0, st>>>(src, n, w.left, w.right, w.parent_leaf, w.node_id, w.node_order, w.leaf_id, w.new_index,
-                                        w.recs, d_nodes, d_tris);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    uint32_t depth = 0;
-    if ((e = hipMemcpyAsync(&depth, w.max_depth, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    radix_pass(st, dst, w.keys_c, m, 32, w.hist);
+    k_level_starts<<<gm, LB_THREADS, 0, st>>>(w.keys_c, m, w.new_index, w.level_start);
+    uint32_t leaf_depth = 0;  // deepest leaf; internal nodes sit at depths 0 .. leaf_depth - 1
+    if ((e = hipMemcpyAsync(&leaf_depth, w.max_depth, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-    *h_height = (int)depth + 1;
+    if (leaf_depth < 1 || leaf_depth > 255) return hipErrorUnknown;
+    for (int level = (int)leaf_depth - 1; level >= 0; --level) {
+        // a level of a binary tree holds at most 2^level nodes, and at most m
+        long long cap = level < 30 ? (1ll << level) : (long long)m;
+        if (cap > m) cap = m;
+        int blocks = (int)((cap + LB_THREADS - 1) / LB_THREADS);
+        if (blocks > 4096) blocks = 4096;
+        k_fit_level<<<blocks, LB_THREADS, 0, st>>>(w.keys_c, w.level_start, level, src, d_tris, w.left, w.right, w.node_id, w.leaf_id,
+                                                   w.new_index, d_nodes);
+    }
+    k_ranks<<<gn, LB_THREADS, 0, st>>>(src, n, w.right, w.parent_leaf, w.node_order, d_tris);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    *h_height = (int)leaf_depth + 1;
     return hipSuccess;
 }

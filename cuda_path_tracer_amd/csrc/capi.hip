@@ -270,28 +270,38 @@ static int validate_scene(cpt_ctx* c, const cpt_scene_desc* s, int* measured_hei
     return CPT_OK;
 }
 
-// One shading record per triangle: geometry, vertex normals and a copy of its material.
+// One shading record per triangle: geometry, vertex normals and a copy of its material.  The material part
+// (lobe probabilities, log kt) is computed here, once per material; a kernel then writes the per-triangle
+// records from the triangles already on the device and the vertex normals.
 static int upload_shading(cpt_ctx* c, const cpt_scene_desc* s) {
-    std::vector<ShadeRec> recs((size_t)s->n_tris);
-    for (int i = 0; i < s->n_tris; ++i) {
-        const cpt_tri& t = s->tris[i];
-        const cpt_tri_normals& tn = s->tri_normals[i];
-        const cpt_material& m = s->materials[t.material];
-        ShadeRec& r = recs[(size_t)i];
+    std::vector<ShadeRec> by_material((size_t)s->n_materials);
+    for (int i = 0; i < s->n_materials; ++i) {
+        const cpt_material& m = s->materials[i];
+        ShadeRec& r = by_material[(size_t)i];
         memset(&r, 0, sizeof r);
-        r.tri_flags = t.flags;
         r.mat_flags = m.flags;
         const LobeProb pr = lobe_probabilities(m.kd, m.ks, m.kt);
         r.p_diff = pr.diff; r.p_spec = pr.spec; r.p_trans = pr.trans;
         r.index = m.index;
         for (int k = 0; k < 3; ++k) {
-            r.n[k] = t.n[k]; r.a[k] = t.a[k]; r.b[k] = t.b[k]; r.c[k] = t.c[k];
-            r.na[k] = tn.na[k]; r.nb[k] = tn.nb[k]; r.nc[k] = tn.nc[k];
             r.ke[k] = m.ke[k]; r.kd[k] = m.kd[k]; r.ks[k] = m.ks[k]; r.kr[k] = m.kr[k]; r.kt[k] = m.kt[k];
             r.log_kt[k] = std::log(m.kt[k]);  // -inf for kt = 0, NaN for kt < 0: the kernel then falls back to pow
         }
     }
-    HIP_TRY(c, hipMemcpy(c->d_shade, recs.data(), sizeof(ShadeRec) * recs.size(), hipMemcpyHostToDevice));
+    void *d_mat = nullptr, *d_normals = nullptr;
+    hipError_t e = hipMalloc(&d_mat, sizeof(ShadeRec) * by_material.size());
+    if (e == hipSuccess) e = hipMalloc(&d_normals, sizeof(cpt_tri_normals) * (size_t)s->n_tris);
+    if (e == hipSuccess) e = hipMemcpy(d_mat, by_material.data(), sizeof(ShadeRec) * by_material.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_normals, s->tri_normals, sizeof(cpt_tri_normals) * (size_t)s->n_tris, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_build_shade(c->stream, (const cpt_tri*)c->d_tris, (const cpt_tri_normals*)d_normals, (const ShadeRec*)d_mat, s->n_tris,
+                           (ShadeRec*)c->d_shade);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_mat);
+    (void)hipFree(d_normals);
+    if (e != hipSuccess) return fail(c, CPT_EHIP, "shading records: %s", hipGetErrorString(e));
     return CPT_OK;
 }
 
@@ -362,11 +372,8 @@ int cpt_build_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     HIP_TRY(c, hipMalloc(&c->d_nodes, sizeof(cpt_node) * (size_t)std::max(n - 1, 1)));
     HIP_TRY(c, hipMalloc(&c->d_tris, sizeof(cpt_tri) * (size_t)n));
     HIP_TRY(c, hipMalloc(&c->d_shade, sizeof(ShadeRec) * (size_t)n));
-    {
-        std::vector<cpt_tri> tris(s->tris, s->tris + n);
-        for (cpt_tri& t : tris) t.test_rank = 0;
-        HIP_TRY(c, hipMemcpy(c->d_tris, tris.data(), sizeof(cpt_tri) * (size_t)n, hipMemcpyHostToDevice));
-    }
+    // test_rank is written by the build; with one triangle there are no ties to break
+    HIP_TRY(c, hipMemcpy(c->d_tris, s->tris, sizeof(cpt_tri) * (size_t)n, hipMemcpyHostToDevice));
     rc = upload_shading(c, s);
     if (rc != CPT_OK) return rc;
     int height = 1;

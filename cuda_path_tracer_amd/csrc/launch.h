@@ -134,7 +134,9 @@ void launch_path_radiance(const LaunchCfg& L, const DScene& sc, const DParams& P
 void launch_probe_math(const LaunchCfg& L, int n, const double* a, const double* b, double* s, double* q);
 void launch_probe_rng(const LaunchCfg& L, const uint32_t c[4], const uint32_t k[2], uint32_t* out, double* out_u);
 
-// Device-side BVH construction (bvh_device.hip).
+// Device-side scene preparation (bvh_device.hip).
+void launch_build_shade(hipStream_t st, const cpt_tri* d_tris, const cpt_tri_normals* d_normals, const ShadeRec* d_by_material,
+                        int n_tris, ShadeRec* d_out);
 size_t lbvh_work_bytes(int n_tris);
 hipError_t launch_lbvh_build(hipStream_t st, cpt_tri* d_tris, int n_tris, cpt_node* d_nodes, void* d_work, int morton_bits,
                              int* h_height);

@@ -68,7 +68,7 @@ cpt_scene_desc FlatScene::describe() const {
     return d;
 }
 
-FlatScene flatten_scene(const RayScene& scene) {
+FlatScene flatten_scene(const RayScene& scene, bool build_tree) {
     FlatScene f;
     f.warnings = scene.warnings;
     put(f.camera.eye, scene.camera.eye);
@@ -110,11 +110,13 @@ FlatScene flatten_scene(const RayScene& scene) {
         }
     }
     if (f.tris.empty()) throw std::runtime_error("scene has no polymesh triangles to render");
-    f.bvh = build_bvh(bounds);
-    emit_records(f.bvh, f.nodes);
+    if (build_tree) {
+        f.bvh = build_bvh(bounds);
+        emit_records(f.bvh, f.nodes);
+    }
     return f;
 }
 
-FlatScene load_flat_scene(const std::string& ray_path) { return flatten_scene(read_ray_file(ray_path)); }
+FlatScene load_flat_scene(const std::string& ray_path, bool build_tree) { return flatten_scene(read_ray_file(ray_path), build_tree); }
 
 }  // namespace cpt

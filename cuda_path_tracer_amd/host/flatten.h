@@ -27,7 +27,8 @@ struct FlatScene {
     cpt_scene_desc describe() const;
 };
 
-FlatScene flatten_scene(const RayScene& scene);
-FlatScene load_flat_scene(const std::string& ray_path);
+// build_tree = false leaves `bvh` and `nodes` empty, for callers that have the GPU build the tree (cpt_build_scene).
+FlatScene flatten_scene(const RayScene& scene, bool build_tree = true);
+FlatScene load_flat_scene(const std::string& ray_path, bool build_tree = true);
 
 }  // namespace cpt

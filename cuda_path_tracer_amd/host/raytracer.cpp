@@ -17,7 +17,7 @@ RayTracer::~RayTracer() {
 bool RayTracer::loadScene(const char* fn) {
     error_.clear();
     try {
-        scene_.reset(new FlatScene(load_flat_scene(fn)));
+        scene_.reset(new FlatScene(load_flat_scene(fn, !options.device_bvh)));
     } catch (const std::exception& e) {
         scene_.reset();
         error_ = e.what();
@@ -67,7 +67,8 @@ void RayTracer::renderGPU(int w, int h, int mode) {
     }
     if (!uploaded_) {
         cpt_scene_desc d = scene_->describe();
-        if (cpt_upload_scene(ctx_, &d) != CPT_OK) { error_ = cpt_last_error(ctx_); return; }
+        const bool on_device = scene_->nodes.empty() && scene_->tris.size() > 1;  // loaded without a host tree
+        if ((on_device ? cpt_build_scene(ctx_, &d) : cpt_upload_scene(ctx_, &d)) != CPT_OK) { error_ = cpt_last_error(ctx_); return; }
         uploaded_ = true;
     }
     if ((size_t)w * h * 3 != buffer_.size()) traceSetup(w, h, true, samples_per_pixel_, depth_);

@@ -21,6 +21,7 @@ struct PathTracingOptions {  // what the reference hard-codes in traceImageGPU (
     unsigned long long seed = 1984;
     int device = 0;
     // long renders (no counterpart in the reference)
+    bool device_bvh = false;        // build the BVH on the GPU (cpt_build_scene) instead of on the host; set before loadScene
     int progressive_spp = 0;        // > 0: refresh the image every this many samples and call on_progress
     std::string checkpoint;         // non-empty: resume from this file if it matches, and save the sums to it
     bool (*on_progress)(void* user, int samples, const unsigned char* rgb, int w, int h) = nullptr;  // true = stop

@@ -95,3 +95,49 @@ def write_image(path, rgb_bottom_up):
     err = C.create_string_buffer(512)
     if _capi.host().cpth_write_image(os.fsencode(path), w, h, a.ctypes.data_as(C.c_void_p), err, 512) != 0:
         raise RuntimeError(err.value.decode())
+
+
+TRI_DTYPE = np.dtype([("a", "f8", 3), ("b", "f8", 3), ("c", "f8", 3), ("n", "f8", 3), ("material", "i4"),
+                      ("flags", "u4"), ("test_rank", "u4"), ("pad", "i4", 5)])
+
+
+class ArrayScene:
+    """Triangles handed over as arrays, without a tree: for Renderer.build, which has the GPU build the BVH.
+
+    vertices: (n, 3, 3) float64.  One diffuse grey material unless `material` (a _capi.Material) is given;
+    triangles are two-sided when `two_sided`.  The camera looks down -z from `eye`."""
+
+    def __init__(self, vertices, material=None, two_sided=True, eye=(0.0, 0.0, 5.0)):
+        v = np.ascontiguousarray(vertices, np.float64)
+        n = v.shape[0]
+        self._tris = np.zeros(n, TRI_DTYPE)
+        self._tris["a"], self._tris["b"], self._tris["c"] = v[:, 0], v[:, 1], v[:, 2]
+        nrm = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+        self._tris["n"] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+        self._tris["flags"] = 1 if two_sided else 0
+        self._normals = np.zeros((n, 9), np.float64)
+        if material is None:
+            material = _capi.Material()
+            for k in range(3):
+                material.kd[k] = 0.5
+            material.flags = 1  # diffuse
+        self._material = material
+        self.desc = _capi.SceneDesc()
+        self.desc.n_tris, self.desc.n_materials = n, 1
+        self.desc.n_tree_nodes = 2 * n - 1
+        self.desc.tris = C.cast(self._tris.ctypes.data, C.POINTER(_capi.Tri))
+        self.desc.tri_normals = C.cast(self._normals.ctypes.data, C.POINTER(_capi.TriNormals))
+        self.desc.materials = C.pointer(self._material)
+        cam = self.desc.camera
+        for k in range(3):
+            cam.eye[k] = eye[k]
+            cam.look[k] = (0.0, 0.0, -1.0)[k]
+            cam.u[k] = (1.0, 0.0, 0.0)[k]
+            cam.v[k] = (0.0, 1.0, 0.0)[k]
+        self.aspect = 1.0
+
+    n_tris = property(lambda s: s.desc.n_tris)
+    n_tree_nodes = property(lambda s: s.desc.n_tree_nodes)
+
+    def tris(self):
+        return self._tris
