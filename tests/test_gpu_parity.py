@@ -163,6 +163,34 @@ def test_sample_ranges_add_up_and_batching_does_not_matter(gpu_scene):
     assert np.array_equal(bits(whole.cpu().numpy()), bits(parts.cpu().numpy()))
 
 
+@pytest.mark.parametrize("name,width,spp,dof", [("cornell-box2-specular", 512, 256, False), ("dragon-spec", 1024, 1024, False),
+                                                ("teapot-trans", 1024, 4096, True)])
+def test_full_size_renders_split_anywhere_add_up(name, width, spp, dof, gpu_scene):
+    """The benchmark configurations at their full sizes, through a property that needs no oracle: a render in
+    one call and the same sample range split at an odd index (and, within each part, into whatever batches and
+    streams the library picks for that size) hold the same radiance sums bit for bit; the image is finite and
+    not empty; with the thin lens on, it is not the pin-hole image."""
+    import torch
+    g = gpu_scene(name)
+    depth = 8
+    h = width
+    p = dict(dof=dof, focal_distance=8.1, aperture=0.6)
+    whole = torch.zeros(h, width, 3, dtype=torch.float64, device="cuda")
+    g.render_into(whole.data_ptr(), g.params(width, h, 0, spp, depth, **p))
+    parts = torch.zeros(h, width, 3, dtype=torch.float64, device="cuda")
+    cut = spp // 3 + 1
+    g.render_into(parts.data_ptr(), g.params(width, h, 0, cut, depth, **p))
+    g.render_into(parts.data_ptr(), g.params(width, h, cut, spp, depth, **p))
+    g.synchronize()
+    assert torch.equal(whole.view(torch.int64), parts.view(torch.int64))
+    assert bool(torch.isfinite(whole).all()) and float(whole.sum()) > 0.0
+    if dof:
+        pin = torch.zeros(h, width, 3, dtype=torch.float64, device="cuda")
+        g.render_into(pin.data_ptr(), g.params(width, h, 0, 16, depth))
+        g.synchronize()
+        assert float((pin / 16 - whole / spp).abs().mean()) > 1e-3
+
+
 def test_tonemap_and_render_image(gpu_scene, oracle):
     import torch
     g = gpu_scene("cornell-box2")
