@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="batches in flight at once (library default when 0)")
+    ap.add_argument("--device-bvh", action="store_true",
+                    help="have the GPU build the BVH (a Morton-order tree) instead of uploading the reference's tree; "
+                         "same image up to ties, different visit sets, so not the parity configuration")
     ap.add_argument("--opt", action="append", default=[], help="key=value passed to cpt_set_option (tuning experiments)")
     args = ap.parse_args()
 
@@ -143,7 +146,10 @@ def main():
         for kv in args.opt:
             k, v = kv.split("=")
             r.set_option(k, int(v))
-        r.upload(hs)
+        if args.device_bvh:
+            r.build(hs)
+        else:
+            r.upload(hs)
         w = wl["width"]
         h = hs.height_for_width(w)
         acc = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
@@ -242,7 +248,8 @@ def main():
         out = {"metric": "Mpaths/s", "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": wl["desc"], "mode": args.mode, "paths_per_step": world * paths_per_step_per_gpu,
+               "config": {"workload": wl["desc"], "mode": args.mode,
+                          "bvh": "built on the GPU (Morton order)" if args.device_bvh else "reference tree (host build)", "paths_per_step": world * paths_per_step_per_gpu,
                           "sharding": "spp range per rank, fp64 radiance reduce to rank 0" if world > 1 else "single GPU"},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
