@@ -361,6 +361,7 @@ int cpt_build_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     if (!c || !s) return CPT_EINVAL;
     int rc = validate_triangles(c, s);
     if (rc != CPT_OK) return rc;
+    if (s->n_tris > (1 << 28)) return fail(c, CPT_ELIMIT, "device BVH build takes at most 2^28 triangles, got %d", s->n_tris);
     for (int i = 0; i < s->n_tris; ++i)  // Morton codes and box unions need finite vertices
         for (int k = 0; k < 3; ++k)
             if (!std::isfinite(s->tris[i].a[k]) || !std::isfinite(s->tris[i].b[k]) || !std::isfinite(s->tris[i].c[k]))
