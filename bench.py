@@ -120,6 +120,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        # communicator set-up (seconds for RCCL) must never land in the timed region, whatever --warmup says
+        probe = torch.ones(1, dtype=torch.float64, device="cuda")
+        reduce_radiance(probe, dst=0)
+        torch.cuda.synchronize()
 
     verbose = bool(os.environ.get("CPT_BENCH_VERBOSE"))
 
