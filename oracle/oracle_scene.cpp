@@ -258,7 +258,7 @@ void read_mesh(Lex& L, Scene& sc, const Material& parent, std::map<std::string, 
     int vc = (int)me.verts.size();
     for (size_t f = 0; f + 2 < faces.size(); f += 3) {
         int a = faces[f], b = faces[f + 1], c = faces[f + 2];
-        if (a >= vc || b >= vc || c >= vc) throw std::runtime_error("bad face in trimesh");
+        if (a < 0 || b < 0 || c < 0 || a >= vc || b >= vc || c >= vc) throw std::runtime_error("bad face in trimesh");  // the reference checks the upper bound only
         V3 A = me.verts[a], B = me.verts[b], C = me.verts[c];
         if (length(B - A) == 0.0 || length(C - A) == 0.0 || length(B - C) == 0.0) continue;  // degenerate: dropped
         me.face_ids.push_back(a); me.face_ids.push_back(b); me.face_ids.push_back(c);
