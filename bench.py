@@ -233,6 +233,17 @@ def main():
                 traffic = json.load(open(tfile)).get(args.workload, {}).get(kernel)
             except Exception:
                 traffic = None
+        # fp64 instruction issue, the resource the extend kernel actually runs out of: instructions per lane on its two
+        # hot paths (counted in the kernel's ISA: 75 per node expansion with both box tests, 89 per triangle test)
+        # against 256 CUs x 4 SIMDs x 16 lanes per cycle at 2.4 GHz.  `useful` counts lanes that had work,
+        # `occupied` every lane of the passes that ran.
+        fp64_peak = 256 * 4 * 16 * 2.4e9
+        fp64 = None
+        if mode == MODE_WAVEFRONT and ms > 0:
+            useful = 75.0 * agg["node_steps"] + 89.0 * agg["tri_tests"]
+            occupied = 75.0 * 64 * agg["box_passes"] + 89.0 * 64 * agg["leaf_passes"]
+            fp64 = {"per_node_step": 75, "per_triangle_test": 89, "peak_Tinstr_per_s": fp64_peak / 1e12,
+                    "useful_frac": useful / (ms * 1e-3) / fp64_peak, "occupied_frac": occupied / (ms * 1e-3) / fp64_peak}
         roof = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "bytes_per_launch": kbytes / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
@@ -242,7 +253,7 @@ def main():
                         "bytes per launch) is far below bytes_per_launch; the kernel's physical bound is fp64 VALU issue",
                 "lane_slots_used": {"box": agg["node_steps"] / max(64 * agg["box_passes"], 1),
                                     "triangle": agg["tri_tests"] / max(64 * agg["leaf_passes"], 1)},
-                "exact_box_fallbacks": agg["exact_node_steps"],
+                "exact_box_fallbacks": agg["exact_node_steps"], "fp64_issue": fp64,
                 "pipeline_GBps": pipeline_bytes(agg) / (sum(t["ms_total"] for t in timed) * 1e-3) / 1e9,
                 "per_segment": {"node_steps": agg["node_steps"] / max(agg["segments"], 1),
                                 "tri_tests": agg["tri_tests"] / max(agg["segments"], 1),
