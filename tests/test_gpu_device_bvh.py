@@ -230,14 +230,18 @@ def test_small_and_degenerate_inputs(gpu, oracle, tmp_path):
         nodes, rank, height = gpu.download_tree()
         if hs.n_tris == 1:
             assert len(nodes) == 0 and height == 1
-            continue
-        check_structure(nodes, rank, height, hs.tris())
+        else:
+            check_structure(nodes, rank, height, hs.tris())
         if label == "coincident":
             assert height <= 10  # ceil(log2 300) + 1
         path = tmp_path / (label + ".ray")
         path.write_text(text)
         orc = oracle.OracleScene(str(path))
         boxes, topo = tree_table(nodes, hs.n_tris)
+        if hs.n_tris == 1:  # the root is the leaf: its box is the triangle's bounds
+            t = hs.tris()[0]
+            pts = np.stack([t["a"], t["b"], t["c"]])
+            boxes[0, :3], boxes[0, 3:] = pts.min(axis=0), pts.max(axis=0) + np.array([0.0, 0.0, 0.5])
         orc.set_tree(boxes, topo)
         compare_with_oracle_on_same_tree(gpu, orc, boxes, 3000, 5)
 
