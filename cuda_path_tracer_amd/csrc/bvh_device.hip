@@ -99,10 +99,12 @@ __global__ void k_morton(const cpt_tri* __restrict__ tris, int n, const unsigned
     if (i >= n) return;
     Box b = tri_box(tris[i]);
     uint32_t q[3];
+    double wmax = 0.0;  // one cell size for all axes: cubical cells
+    for (int k = 0; k < 3; ++k) wmax = fmax(wmax, unordered(bounds[3 + k]) - unordered(bounds[k]));
     for (int k = 0; k < 3; ++k) {
-        double lo = unordered(bounds[k]), hi = unordered(bounds[3 + k]);
+        double lo = unordered(bounds[k]);
         double c = 0.5 * (b.lo[k] + b.hi[k]);
-        double w = hi - lo;
+        double w = wmax;
         double u = w > 0.0 ? (c - lo) / w : 0.0;
         int cell = (int)(u * 1024.0);
         cell = cell < 0 ? 0 : (cell > 1023 ? 1023 : cell);
