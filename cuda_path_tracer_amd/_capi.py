@@ -54,7 +54,8 @@ class SceneDesc(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("sample_begin", C.c_int32), ("sample_end", C.c_int32),
                 ("depth", C.c_int32), ("mode", C.c_int32), ("seed", C.c_uint64), ("dof", C.c_int32),
-                ("russian_roulette", C.c_int32), ("focal_distance", C.c_double), ("aperture", C.c_double)]
+                ("russian_roulette", C.c_int32), ("focal_distance", C.c_double), ("aperture", C.c_double),
+                ("tile_begin", C.c_int32), ("tile_count", C.c_int32)]
 
 
 class Stats(C.Structure):

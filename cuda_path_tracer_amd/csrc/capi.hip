@@ -471,8 +471,25 @@ static int make_params(cpt_ctx* c, const cpt_render_params* p, DParams& P) {
     P.seed_lo = (uint32_t)p->seed; P.seed_hi = (uint32_t)(p->seed >> 32);
     P.focal_distance = p->focal_distance; P.aperture = p->aperture;
     P.tiles_x = (p->width + 7) / 8; P.tiles_y = (p->height + 7) / 8;
-    P.n_pix_slots = P.tiles_x * P.tiles_y * 64;
+    const int n_tiles = P.tiles_x * P.tiles_y;
+    if (p->tile_count < 0 || p->tile_begin < 0 || (p->tile_count == 0 && p->tile_begin != 0) ||
+        (long long)p->tile_begin + p->tile_count > n_tiles)
+        return fail(c, CPT_EINVAL, "bad tile window [%d, +%d) of %d tiles", p->tile_begin, p->tile_count, n_tiles);
+    P.tile0 = p->tile_begin;
+    P.n_pix_slots = (p->tile_count > 0 ? p->tile_count : n_tiles) * 64;
     return CPT_OK;
+}
+
+// Pixels of the image that lie in the tile window of P (edge tiles are partly outside the image).
+static long long window_pixels(const DParams& P) {
+    const int n_tiles = P.n_pix_slots / 64;
+    if (P.tile0 == 0 && n_tiles == P.tiles_x * P.tiles_y) return (long long)P.w * P.h;
+    long long n = 0;
+    for (int t = P.tile0; t < P.tile0 + n_tiles; ++t) {
+        const int tx = t % P.tiles_x, ty = t / P.tiles_x;
+        n += (long long)std::min(8, P.w - tx * 8) * std::min(8, P.h - ty * 8);
+    }
+    return n;
 }
 
 static int need_events(cpt_ctx* c, size_t n) {
@@ -510,7 +527,7 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
     LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     unsigned long long* work = c->count_work ? c->d_work : nullptr;
     const bool timed = c->time_kernels;
-    long long n_paths = (long long)P.w * P.h * (P.s1 - P.s0);
+    long long n_paths = window_pixels(P) * (P.s1 - P.s0);
 
     if (p->mode == CPT_MODE_MEGAKERNEL) {
         if (timed) { rc = need_events(c, 2); if (rc) return rc; HIP_TRY(c, hipEventRecord(c->events[0], c->stream)); }

@@ -503,7 +503,7 @@ __device__ __forceinline__ bool shade_bounce(const DScene& sc, const DParams& P,
 // processes 64 consecutive slots hold one tile: neighbouring first rays, one coalesced block of
 // state.  Slots whose pixel falls outside the image are never generated.
 __device__ __forceinline__ bool slot_to_pixel(const DParams& P, int slot, int& i, int& j) {
-    int tile = slot >> 6, in = slot & 63;
+    int tile = P.tile0 + (slot >> 6), in = slot & 63;
     int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
     i = tx * 8 + (in & 7);
     j = ty * 8 + (in >> 3);

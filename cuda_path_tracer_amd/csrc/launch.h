@@ -57,7 +57,8 @@ struct DParams {  // cpt_render_params plus what the kernels derive from it
     uint32_t seed_lo, seed_hi;
     double focal_distance, aperture;
     int tiles_x, tiles_y;  // 8x8 pixel tiles
-    int n_pix_slots;       // tiles_x*tiles_y*64
+    int n_pix_slots;       // 64 per tile of the window being rendered (the whole image: tiles_x*tiles_y*64)
+    int tile0;             // first tile of the window
 };
 
 

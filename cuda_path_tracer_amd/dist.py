@@ -1,5 +1,6 @@
-"""Multi-GPU sharding of one render: one process per GPU, samples-per-pixel split across ranks,
-per-rank radiance sums combined with one reduce (RCCL over xGMI when the tensors are on GPUs).
+"""Multi-GPU sharding of one render: one process per GPU, samples-per-pixel split across ranks (or, when there
+are fewer samples than ranks, the image's tiles), per-rank radiance sums combined with one reduce (RCCL over
+xGMI when the tensors are on GPUs).
 
 The reference is single-GPU; this has no counterpart there.  Because every random number is
 addressed by (pixel, sample, bounce), rank r rendering samples [b_r, e_r) produces exactly the
@@ -16,6 +17,15 @@ def sample_range(rank, world, first, count):
     base, extra = divmod(count, world)
     begin = first + rank * base + min(rank, extra)
     return begin, begin + base + (1 if rank < extra else 0)
+
+
+def tile_range(rank, world, width, height):
+    """Share of the image's 8x8-pixel tiles for `rank` of `world`, as (tile_begin, tile_count) for
+    Renderer.params: the way to split one render by area instead of by samples (fewer samples than GPUs, or a
+    single sample to be finished sooner).  Tiles are numbered row by row; ranks get contiguous runs."""
+    n_tiles = ((width + 7) // 8) * ((height + 7) // 8)
+    begin, end = sample_range(rank, world, 0, n_tiles)
+    return begin, end - begin
 
 
 def reduce_radiance(accum, dst=0, group=None):

@@ -89,10 +89,10 @@ class Renderer:
 
     @staticmethod
     def params(width, height, sample_begin, sample_end, depth, mode=MODE_WAVEFRONT, seed=1984, dof=False,
-               focal_distance=8.5, aperture=0.6, russian_roulette=False):
+               focal_distance=8.5, aperture=0.6, russian_roulette=False, tile_begin=0, tile_count=0):
         return _capi.RenderParams(int(width), int(height), int(sample_begin), int(sample_end), int(depth), int(mode),
                                   int(seed), int(bool(dof)), int(bool(russian_roulette)), float(focal_distance),
-                                  float(aperture))
+                                  float(aperture), int(tile_begin), int(tile_count))
 
     # --- rendering ------------------------------------------------------------------------------
     def render_into(self, accum_ptr, params):

@@ -114,6 +114,12 @@ typedef struct cpt_render_params {
     int32_t dof;                      /* 0: pin-hole; 1: thin lens (src/path_tracer.cu:446-492)       */
     int32_t russian_roulette;         /* 0 (reference behaviour) or 1                                 */
     double focal_distance, aperture;  /* reference constants: 8.5, 0.6 (src/path_tracer.cu:512-514)   */
+    int32_t tile_begin, tile_count;   /* render only the 8x8-pixel tiles [tile_begin, tile_begin + tile_count) of the
+                                         image, tiles numbered row by row, (width + 7) / 8 per row; tile_count 0 =
+                                         the whole image.  The accumulation buffer is always the whole image's; pixels
+                                         outside the window are not touched.  A pixel's paths do not depend on the
+                                         window, so disjoint windows add up to the full render bit for bit: the way to
+                                         shard one render over GPUs by area when there are fewer samples than GPUs. */
 } cpt_render_params;
 
 typedef struct cpt_stats {

@@ -56,3 +56,15 @@ def test_two_rank_reduce_equals_single_render(tmp_path, oracle_scenes):
     # same sample set; only the order of the last addition differs
     assert np.allclose(got, want, rtol=1e-13, atol=1e-15)
     assert got.sum() > 0
+
+
+def test_tile_range_partitions_the_tiles():
+    from cuda_path_tracer_amd.dist import tile_range
+    for (w, h, world) in [(512, 512, 8), (37, 23, 4), (8, 8, 3), (1000, 3, 7)]:
+        n_tiles = ((w + 7) // 8) * ((h + 7) // 8)
+        covered = []
+        for r in range(world):
+            b, c = tile_range(r, world, w, h)
+            assert 0 <= b and c >= 0 and b + c <= n_tiles
+            covered.extend(range(b, b + c))
+        assert covered == list(range(n_tiles))  # contiguous, disjoint, complete, in rank order

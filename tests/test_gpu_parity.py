@@ -191,6 +191,42 @@ def test_full_size_renders_split_anywhere_add_up(name, width, spp, dof, gpu_scen
         assert float((pin / 16 - whole / spp).abs().mean()) > 1e-3
 
 
+def test_tile_windows_add_up_to_the_full_render(gpu_scene):
+    """Rendering disjoint tile windows into one buffer gives the full render bit for bit (both kernels shapes,
+    ragged image sides); a window leaves the pixels outside it alone; bad windows are refused."""
+    import torch
+    from cuda_path_tracer_amd import CptError
+    from cuda_path_tracer_amd.dist import tile_range
+    g = gpu_scene("cornell-box2-transmissive")
+    w, h, spp, depth = 77, 43, 5, 5
+    n_tiles = ((w + 7) // 8) * ((h + 7) // 8)
+    for mode in (0, 1):
+        whole = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+        g.render_into(whole.data_ptr(), g.params(w, h, 0, spp, depth, mode=mode))
+        parts = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+        for r in range(3):
+            b, c = tile_range(r, 3, w, h)
+            g.render_into(parts.data_ptr(), g.params(w, h, 0, spp, depth, mode=mode, tile_begin=b, tile_count=c))
+        g.synchronize()
+        assert torch.equal(whole.view(torch.int64), parts.view(torch.int64))
+    one = torch.full((h, w, 3), 7.0, dtype=torch.float64, device="cuda")
+    g.render_into(one.data_ptr(), g.params(w, h, 0, spp, depth, tile_begin=11, tile_count=1))  # tile (1, 1): pixels 8..15 x 8..15
+    g.synchronize()
+    touched = (one != 7.0).any(dim=2).cpu().numpy()
+    assert touched[8:16, 8:16].any() and not touched[:8].any() and not touched[16:].any() and not touched[:, :8].any() and not touched[:, 16:].any()
+    g.reset_stats()
+    g.set_instrumentation(False, True)
+    try:
+        g.render_into(one.data_ptr(), g.params(w, h, 0, 2, depth, tile_begin=n_tiles - 1, tile_count=1))  # the ragged corner tile
+        g.synchronize()
+        assert g.stats()["paths"] == 2 * (w - 72) * (h - 40)
+    finally:
+        g.set_instrumentation(False, False)
+    for (b, c) in [(0, n_tiles + 1), (n_tiles, 1), (-1, 2), (3, 0), (0, -1)]:
+        with pytest.raises(CptError):
+            g.render_into(one.data_ptr(), g.params(w, h, 0, 1, depth, tile_begin=b, tile_count=c))
+
+
 def test_tonemap_and_render_image(gpu_scene, oracle):
     import torch
     g = gpu_scene("cornell-box2")
