@@ -471,12 +471,15 @@ static int make_params(cpt_ctx* c, const cpt_render_params* p, DParams& P) {
     P.seed_lo = (uint32_t)p->seed; P.seed_hi = (uint32_t)(p->seed >> 32);
     P.focal_distance = p->focal_distance; P.aperture = p->aperture;
     P.tiles_x = (p->width + 7) / 8; P.tiles_y = (p->height + 7) / 8;
+    if ((long long)P.tiles_x * P.tiles_y * 64 > (1ll << 28)) return fail(c, CPT_ELIMIT, "image too large");  // also what fast_div is exact for
     const int n_tiles = P.tiles_x * P.tiles_y;
     if (p->tile_count < 0 || p->tile_begin < 0 || (p->tile_count == 0 && p->tile_begin != 0) ||
         (long long)p->tile_begin + p->tile_count > n_tiles)
         return fail(c, CPT_EINVAL, "bad tile window [%d, +%d) of %d tiles", p->tile_begin, p->tile_count, n_tiles);
     P.tile0 = p->tile_begin;
     P.n_pix_slots = (p->tile_count > 0 ? p->tile_count : n_tiles) * 64;
+    P.by_pix_slots = fast_div_for((uint32_t)P.n_pix_slots);
+    P.by_tiles_x = fast_div_for((uint32_t)P.tiles_x);
     return CPT_OK;
 }
 

@@ -504,7 +504,7 @@ __device__ __forceinline__ bool shade_bounce(const DScene& sc, const DParams& P,
 // state.  Slots whose pixel falls outside the image are never generated.
 __device__ __forceinline__ bool slot_to_pixel(const DParams& P, int slot, int& i, int& j) {
     int tile = P.tile0 + (slot >> 6), in = slot & 63;
-    int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+    int ty = (int)fast_div((uint32_t)tile, P.by_tiles_x), tx = tile - ty * P.tiles_x;
     i = tx * 8 + (in & 7);
     j = ty * 8 + (in >> 3);
     return i < P.w && j < P.h;

@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_generate(DScene sc, DParams P, Ra
                                                         int batch_n) {
     int total = batch_n * P.n_pix_slots;
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += gridDim.x * blockDim.x) {
-        int k = slot / P.n_pix_slots, ps = slot - k * P.n_pix_slots;
+        int k = (int)fast_div((uint32_t)slot, P.by_pix_slots), ps = slot - k * P.n_pix_slots;
         int i, j;
         bool live = slot_to_pixel(P, ps, i, j);
         dvec3 o = dv(1e300, 1e300, 1e300), d = dv(1, 0, 0), atten = dv(0, 0, 0);
@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(CPT_SHADE_BLOCK, 4) k_shade(DScene sc, DParams
             if (COUNT) { segs++; hits += (tri >= 0); }
             if (tri >= 0) {
                 slot = CPT_NT_LOAD(in.slot[q]);
-                int k = (int)slot / P.n_pix_slots, ps = (int)slot - k * P.n_pix_slots;
+                int k = (int)fast_div(slot, P.by_pix_slots), ps = (int)slot - k * P.n_pix_slots;
                 int i, j;
                 slot_to_pixel(P, ps, i, j);
                 uint32_t pixel = (uint32_t)(i + j * P.w), sample = (uint32_t)(batch_s0 + k);

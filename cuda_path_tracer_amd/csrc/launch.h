@@ -51,6 +51,22 @@ struct DScene {
     int n_nodes, n_tris;
 };
 
+// Division of a number below 2^28 by a divisor fixed at launch, as a multiplication and a shift: with
+// L = ceil(log2 d) and m = ceil(2^(28+L) / d) < 2^29, (n * m) >> (28 + L) == n / d for every n < 2^28
+// (Granlund and Montgomery's round-up method).  Path slots, pixel slots and tile numbers are all below 2^28.
+struct FastDiv {
+    uint32_t m, s;
+};
+inline FastDiv fast_div_for(uint32_t d) {
+    uint32_t L = 0;
+    while ((1u << L) < d) ++L;
+    FastDiv f;
+    f.s = 28 + L;
+    f.m = (uint32_t)(((1ull << f.s) + d - 1) / d);
+    return f;
+}
+CPT_HD uint32_t fast_div(uint32_t n, FastDiv f) { return (uint32_t)(((unsigned long long)n * f.m) >> f.s); }
+
 struct DParams {  // cpt_render_params plus what the kernels derive from it
     int w, h, s0, s1, depth;
     int dof, rr;
@@ -59,6 +75,7 @@ struct DParams {  // cpt_render_params plus what the kernels derive from it
     int tiles_x, tiles_y;  // 8x8 pixel tiles
     int n_pix_slots;       // 64 per tile of the window being rendered (the whole image: tiles_x*tiles_y*64)
     int tile0;             // first tile of the window
+    FastDiv by_pix_slots, by_tiles_x;  // division by n_pix_slots and by tiles_x
 };
 
 
