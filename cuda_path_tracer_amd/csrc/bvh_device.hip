@@ -28,6 +28,7 @@
 #include <stdint.h>
 
 #include "launch.h"
+#include "dvec.h"
 
 #define LB_THREADS 256
 #define LB_SORT_TILE 1024  // keys per one-wave workgroup of the sort
@@ -436,12 +437,25 @@ __global__ void k_build_shade(const cpt_tri* __restrict__ tris, const cpt_tri_no
     if (i >= n) return;
     const cpt_tri& t = tris[i];
     const cpt_tri_normals& tn = normals[i];
-    ShadeRec r = by_material[t.material];
+    ShadeRec r = by_material[t.material];  // diff_w holds kd and inv_p_trans holds p_trans on arrival
     r.tri_flags = t.flags;
     for (int k = 0; k < 3; ++k) {
-        r.n[k] = t.n[k]; r.a[k] = t.a[k]; r.b[k] = t.b[k]; r.c[k] = t.c[k];
+        r.a[k] = t.a[k]; r.b[k] = t.b[k]; r.c[k] = t.c[k];
         r.na[k] = tn.na[k]; r.nb[k] = tn.nb[k]; r.nc[k] = tn.nc[k];
     }
+    // per-hit expressions of the shading code whose operands are the same at every hit (same operations, same order)
+    const dvec3 n1 = normalize(dv(t.n)), n2 = normalize(n1);
+    const double pdf = 1 / CPT_PI, theta = 1;
+    const dvec3 brdf = dv(r.diff_w) / CPT_PI;
+    const dvec3 dw = brdf * theta / (pdf * r.p_diff);
+    const dvec3 sw = dv(r.ks) * 1.0 / r.p_spec;
+    r.n1[0] = n1.x; r.n1[1] = n1.y; r.n1[2] = n1.z;
+    r.n2[0] = n2.x; r.n2[1] = n2.y; r.n2[2] = n2.z;
+    r.diff_w[0] = dw.x; r.diff_w[1] = dw.y; r.diff_w[2] = dw.z;
+    r.spec_w[0] = sw.x; r.spec_w[1] = sw.y; r.spec_w[2] = sw.z;
+    r.inv_p_trans = 1 / r.inv_p_trans;
+    double q = (1.0 - r.index) / (1.0 + r.index);
+    r.r0 = q * q;
     out[i] = r;
 }
 

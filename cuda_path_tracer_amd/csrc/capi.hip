@@ -281,10 +281,10 @@ static int upload_shading(cpt_ctx* c, const cpt_scene_desc* s) {
         memset(&r, 0, sizeof r);
         r.mat_flags = m.flags;
         const LobeProb pr = lobe_probabilities(m.kd, m.ks, m.kt);
-        r.p_diff = pr.diff; r.p_spec = pr.spec; r.p_trans = pr.trans;
+        r.p_diff = pr.diff; r.p_spec = pr.spec; r.inv_p_trans = pr.trans;  // the kernel turns p_trans into its reciprocal
         r.index = m.index;
         for (int k = 0; k < 3; ++k) {
-            r.ke[k] = m.ke[k]; r.kd[k] = m.kd[k]; r.ks[k] = m.ks[k]; r.kr[k] = m.kr[k]; r.kt[k] = m.kt[k];
+            r.ke[k] = m.ke[k]; r.diff_w[k] = m.kd[k]; r.ks[k] = m.ks[k]; r.kr[k] = m.kr[k]; r.kt[k] = m.kt[k];  // diff_w: kd for now
             r.log_kt[k] = std::log(m.kt[k]);  // -inf for kt = 0, NaN for kt < 0: the kernel then falls back to pow
         }
     }

@@ -236,8 +236,7 @@ __device__ __forceinline__ void traverse(const DScene& sc, const dvec3& o, const
 // barycentric weights inside every triangle test; only the winning hit's are ever used, so they
 // are computed once here from the same expressions.
 __device__ __forceinline__ dvec3 shading_normal(const ShadeRec* tp, const dvec3& o, const dvec3& d, double t) {
-    dvec3 n = dv(tp->n);
-    if (!(tp->tri_flags & CPT_TRI_VERTEX_NORMALS)) return normalize(n);
+    if (!(tp->tri_flags & CPT_TRI_VERTEX_NORMALS)) return dv(tp->n1);  // normalize(face normal), from the record
     dvec3 a = dv(tp->a), b = dv(tp->b), c = dv(tp->c);
     dvec3 P = o + d * t;
     double alpha = length(cross(b - P, c - P));
@@ -319,7 +318,6 @@ __device__ __forceinline__ void first_ray(const DScene& sc, const DParams& P, in
 }
 
 // ---- one bounce --------------------------------------------------------------------------
-#define CPT_PI 3.14159265358979311600  // reference: src/RayTracer.h:5
 
 // reference: src/path_tracer.cu:242-253
 __device__ __forceinline__ dvec3 cosine_hemisphere(const dvec3& normal, double xa, double xb) {
@@ -391,9 +389,10 @@ __device__ __forceinline__ int choose_lobe(const DScene& sc, const DParams& P, u
 __device__ __forceinline__ void scatter(int lobe, const DScene& sc, const DParams& P, uint32_t pixel, uint32_t sample,
                                         int bounce, double t, int tri, PathRegs& s) {
     const ShadeRec* m = sc.shade + tri;
-    LobeProb pr;
-    pr.diff = m->p_diff; pr.spec = m->p_spec; pr.trans = m->p_trans;
+    const bool flat = !(m->tri_flags & CPT_TRI_VERTEX_NORMALS);
     const dvec3 N = shading_normal(m, s.o, s.d, t);
+    // normalize(N) as the diffuse and mirror lobes take it: for a flat triangle that is in the record too
+    const dvec3 NN = flat ? dv(m->n2) : normalize(N);
     const dvec3 at = s.o + (t * s.d);
 
     bool reflects = false;        // ends in the reflection block below
@@ -403,21 +402,19 @@ __device__ __forceinline__ void scatter(int lobe, const DScene& sc, const DParam
     bool reset_medium = false;
 
     if (lobe == CPT_LOBE_DIFFUSE) {  // :284-293
-        dvec3 normal = normalize(N);
+        dvec3 normal = NN;
         double xa, xb;
         draw2(P, pixel, sample, (uint32_t)bounce, CPT_STREAM_COSINE, xa, xb);
         dvec3 rand_dir = cosine_hemisphere(normal, xa, xb);
-        const double pdf = 1 / CPT_PI, theta = 1;
         s.o = at + normal * 1e-12;
         s.d = rand_dir;
         s.medium = 1.0;
-        dvec3 brdf = dv(m->kd) / CPT_PI;
-        s.atten = s.atten * (brdf * theta / (pdf * pr.diff));
+        s.atten = s.atten * dv(m->diff_w);  // brdf * theta / (pdf * p_diff), brdf = kd / pi, pdf = 1 / pi, theta = 1 (:289-292)
     } else if (lobe == CPT_LOBE_MIRROR) {  // :294-308
         rw = normalize(s.d);
-        rn = normalize(N);
+        rn = NN;
         if (s.medium != 1.0) rn = rn * -1.0;
-        f1 = dv(m->ks) * 1.0 / pr.spec;
+        f1 = dv(m->spec_w);  // ks * 1.0 / p_spec
         reset_medium = true;  // the reference builds a fresh Ray here, which resets the medium (:306)
         reflects = true;
     } else {  // :310-396
@@ -440,8 +437,7 @@ __device__ __forceinline__ void scatter(int lobe, const DScene& sc, const DParam
             tr.y = (kt.y == kt.x) ? tr.x : ((kt.y > 0) ? exp(t * lk.y) : pow(kt.y, t));  // equal inputs give equal results: computed once
             tr.z = (kt.z == kt.x) ? tr.x : ((kt.z == kt.y) ? tr.y : ((kt.z > 0) ? exp(t * lk.z) : pow(kt.z, t)));
         }
-        double r0 = (n1 - n2) / (n1 + n2);
-        r0 *= r0;
+        const double r0 = m->r0;  // ((n1 - n2) / (n1 + n2))^2: the two sides give quotients of opposite sign, one square
         double n = n1 / n2;
         w_in = -normalize(w_in);
         double cosI = dot(normal, w_in);
@@ -462,7 +458,7 @@ __device__ __forceinline__ void scatter(int lobe, const DScene& sc, const DParam
                 s.d = refrac;
                 s.medium = n2;
                 s.atten = s.atten * tr;
-                s.atten = s.atten * (1 / pr.trans);
+                s.atten = s.atten * m->inv_p_trans;
             } else {  // Fresnel reflection about the geometric-side normal, medium kept
                 rw = s.d;
                 rn = N;
@@ -485,7 +481,7 @@ __device__ __forceinline__ void scatter(int lobe, const DScene& sc, const DParam
         s.d = w_ref;
         if (reset_medium) s.medium = 1.0;
         s.atten = s.atten * f1;
-        if (lobe_weight) s.atten = s.atten * (1 / pr.trans);
+        if (lobe_weight) s.atten = s.atten * m->inv_p_trans;
     }
 }
 

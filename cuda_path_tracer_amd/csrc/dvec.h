@@ -6,6 +6,7 @@
 #pragma once
 #include <math.h>
 
+#define CPT_PI 3.14159265358979311600  // reference: src/RayTracer.h:5
 #if defined(__HIPCC__)
 #define CPT_HD __host__ __device__ __forceinline__
 #else

@@ -8,23 +8,33 @@
 
 // Everything the shading half of a bounce needs to know about a triangle, in one record, so a hit
 // costs one dependent fetch (hit -> record) instead of a chain (hit -> triangle -> material, plus the
-// vertex normals).  The first 128 bytes serve a flat-shaded diffuse hit on their own.  The lobe
-// probabilities depend on the material alone and are computed once, at upload, with the
-// reference's expressions (src/path_tracer.cu:272-279).
+// vertex normals), and everything that is the same at every hit of the triangle is worked out once, when
+// the scene is prepared, by the device with the very expressions the reference evaluates per hit
+// (src/path_tracer.cu:272-293, 294-308, 340-343): the normalised face normal and its second
+// normalisation, the lobe probabilities, the diffuse and mirror throughput factors, 1 / p_trans, r0.
+// Four 128-byte lines: the first serves a flat-shaded diffuse hit on its own, the second adds what the
+// mirror and dielectric lobes need, the last two are read for smooth-shaded triangles (and log kt inside
+// a medium).
 struct __attribute__((aligned(128))) ShadeRec {
     uint32_t tri_flags, mat_flags;     // CPT_TRI_*, CPT_MAT_*
-    double n[3];                       // face normal as stored with the triangle
-    double ke[3], kd[3];
-    double p_diff, p_spec, p_trans;    // lobe probabilities
+    double n1[3];                      // normalize(face normal): the shading normal of a flat triangle
+    double n2[3];                      // normalize(n1): what the diffuse and mirror lobes normalise it to again
+    double ke[3];
+    double diff_w[3];                  // (kd / pi) * 1 / ((1 / pi) * p_diff); holds kd until the device fills it in
+    double p_diff, p_spec;             // lobe probabilities
+    double inv_p_trans;                // 1 / p_trans; holds p_trans until the device fills it in
+    double ks[3], kr[3], kt[3];        // second line
+    double spec_w[3];                  // ks * 1.0 / p_spec
     double index;
-    double pad0[2];
-    double ks[3], kr[3], kt[3];        // second 128 bytes: specular / transmissive materials
-    double a[3], b[3], c[3];           // vertices and vertex normals: smooth-shaded triangles only
-    double na[3], nb[3], nc[3];
-    double log_kt[3];                  // log(kt), so that kt^t is one exp() at a hit inside the medium
+    double r0;                         // ((1 - index) / (1 + index))^2, the same from either side
     double pad1[2];
+    double a[3], b[3], c[3];           // third line: vertices, smooth-shaded triangles only
+    double log_kt[3];                  // log(kt), so that kt^t is one exp() at a hit inside the medium
+    double pad2[4];
+    double na[3], nb[3], nc[3];        // fourth line: vertex normals
+    double pad3[7];
 };
-static_assert(sizeof(ShadeRec) == 384, "ShadeRec is three 128-byte lines");
+static_assert(sizeof(ShadeRec) == 512, "ShadeRec is four 128-byte lines");
 
 struct LobeProb {
     double diff, spec, trans;
