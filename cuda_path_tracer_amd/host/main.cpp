@@ -52,6 +52,7 @@ void usage(const char* prog, const Cli& c) {
               << "  --rr        Russian roulette\n"
               << "  --seed <#>  random seed (default 1984)\n"
               << "  --device <#> GPU ordinal (default 0)\n"
+              << "  --devices <#,#,...>  split the samples over these GPUs (one host thread and context each)\n"
               << "  --device-bvh        build the BVH on the GPU (a Morton-order tree, not the reference's)\n"
               << "  --progressive <#>   rewrite the output image every # samples per pixel\n"
               << "  --checkpoint <FILE> resume from FILE if it matches this render, and save the radiance sums to it\n"
@@ -81,7 +82,7 @@ int main(int argc, char** argv) {
                                 {"rr", no_argument, nullptr, 1002},         {"seed", required_argument, nullptr, 1003},
                                 {"device", required_argument, nullptr, 1004}, {"progressive", required_argument, nullptr, 1005},
                                 {"checkpoint", required_argument, nullptr, 1006}, {"metrics", required_argument, nullptr, 1007},
-                                {"device-bvh", no_argument, nullptr, 1008},
+                                {"device-bvh", no_argument, nullptr, 1008},     {"devices", required_argument, nullptr, 1009},
                                 {nullptr, 0, nullptr, 0}};
     int o;
     while ((o = getopt_long(argc, argv, "tr:w:hj:c:gs:", longopts, nullptr)) != -1) {
@@ -110,6 +111,17 @@ int main(int argc, char** argv) {
             case 1006: c.pt.checkpoint = optarg; break;
             case 1007: c.metrics = optarg; break;
             case 1008: c.pt.device_bvh = true; break;
+            case 1009:
+                c.pt.devices.clear();
+                for (const char* q = optarg; *q;) {
+                    char* end = nullptr;
+                    long v = strtol(q, &end, 10);
+                    if (end == q || v < 0) { std::cerr << "--devices wants a comma-separated list of GPU ordinals\n"; return 1; }
+                    c.pt.devices.push_back((int)v);
+                    q = (*end == ',') ? end + 1 : end;
+                    if (*end && *end != ',') { std::cerr << "--devices wants a comma-separated list of GPU ordinals\n"; return 1; }
+                }
+                break;
             default:
                 std::cerr << "Invalid argument: '" << o << "'." << std::endl;
                 usage(argv[0], c);

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <thread>
 
 namespace cpt {
 
@@ -12,6 +13,7 @@ RayTracer::RayTracer() = default;
 
 RayTracer::~RayTracer() {
     if (ctx_) cpt_destroy(ctx_);
+    for (cpt_ctx* c : more_ctx_) if (c) cpt_destroy(c);
 }
 
 bool RayTracer::loadScene(const char* fn) {
@@ -62,8 +64,13 @@ void RayTracer::betterPathTracing(int w, int h) { renderGPU(w, h, CPT_MODE_WAVEF
 void RayTracer::renderGPU(int w, int h, int mode) {
     error_.clear();
     if (!sceneLoaded()) { error_ = "no scene loaded"; return; }
+    const bool multi = options.devices.size() > 1;
+    if (multi && (options.progressive_spp > 0 || !options.checkpoint.empty())) {
+        error_ = "progressive and checkpointed renders run on one GPU";
+        return;
+    }
     if (!ctx_) {
-        if (cpt_create(options.device, &ctx_) != CPT_OK) { error_ = cpt_last_error(nullptr); ctx_ = nullptr; return; }
+        if (cpt_create(multi ? options.devices[0] : options.device, &ctx_) != CPT_OK) { error_ = cpt_last_error(nullptr); ctx_ = nullptr; return; }
     }
     if (!uploaded_) {
         cpt_scene_desc d = scene_->describe();
@@ -83,6 +90,7 @@ void RayTracer::renderGPU(int w, int h, int mode) {
     p.focal_distance = options.focal_distance;
     p.aperture = options.aperture;
     samples_in_image_ = 0;
+    if (multi) { renderMultiGPU(w, h, p); return; }
     if (options.progressive_spp <= 0 && options.checkpoint.empty()) {
         if (cpt_render_image(ctx_, &p, buffer_.data()) != CPT_OK) error_ = cpt_last_error(ctx_);
         else samples_in_image_ = samples_per_pixel_;
@@ -146,6 +154,54 @@ void RayTracer::renderGPU(int w, int h, int mode) {
         if (f) ok = (fclose(f) == 0) && ok;
         if (!ok || rename(tmp.c_str(), options.checkpoint.c_str()) != 0) error_ = "cannot write checkpoint " + options.checkpoint;
     }
+}
+
+// One render on several GPUs of this machine: GPU k of n renders a contiguous share of the sample indices of
+// every pixel (the first spp % n GPUs one more) from a host thread of its own, through a context of its own, and
+// hands back fp64 radiance sums; they are added in list order and tonemapped with k_tonemap's formula.  A
+// sample's paths depend only on (pixel, sample index, seed), so the sample set is the single-GPU one; only the
+// association of the final additions differs.  No reference counterpart (the reference drives one GPU).
+void RayTracer::renderMultiGPU(int w, int h, const cpt_render_params& p) {
+    const size_t n = options.devices.size();
+    more_ctx_.resize(n - 1, nullptr);
+    const cpt_scene_desc d = scene_->describe();
+    const bool on_device = scene_->nodes.empty() && scene_->tris.size() > 1;
+    std::vector<std::vector<double>> sums(n, std::vector<double>((size_t)w * h * 3, 0.0));
+    std::vector<std::string> errors(n);
+    std::vector<int> done(n, 0);
+    auto work = [&](size_t k) {
+        cpt_ctx*& c = k == 0 ? ctx_ : more_ctx_[k - 1];
+        if (!c && cpt_create(options.devices[k], &c) != CPT_OK) { errors[k] = cpt_last_error(nullptr); c = nullptr; return; }
+        if (k > 0 && (on_device ? cpt_build_scene(c, &d) : cpt_upload_scene(c, &d)) != CPT_OK) { errors[k] = cpt_last_error(c); return; }
+        const int total = p.sample_end - p.sample_begin, base = total / (int)n, extra = total % (int)n;
+        cpt_render_params q = p;
+        q.sample_begin = p.sample_begin + (int)k * base + std::min((int)k, extra);
+        q.sample_end = q.sample_begin + base + ((int)k < extra ? 1 : 0);
+        if (q.sample_end == q.sample_begin) return;
+        std::vector<unsigned char> rgb((size_t)w * h * 3);
+        int32_t got = 0;
+        if (cpt_render_progressive(c, &q, q.sample_end - q.sample_begin, sums[k].data(), 0, rgb.data(), nullptr, nullptr, &got) != CPT_OK) {
+            errors[k] = cpt_last_error(c);
+            return;
+        }
+        done[k] = got;
+    };
+    std::vector<std::thread> pool;
+    for (size_t k = 1; k < n; ++k) pool.emplace_back(work, k);
+    work(0);
+    for (std::thread& t : pool) t.join();
+    for (size_t k = 0; k < n; ++k)
+        if (!errors[k].empty()) { error_ = "GPU " + std::to_string(options.devices[k]) + ": " + errors[k]; return; }
+    int have = 0;
+    for (size_t k = 0; k < n; ++k) have += done[k];
+    for (size_t i = 0; i < sums[0].size(); ++i) {
+        double sum = sums[0][i];
+        for (size_t k = 1; k < n; ++k) sum += sums[k][i];
+        double c = sum / have;
+        c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+        buffer_[i] = (unsigned char)(int)(255.0 * c);
+    }
+    samples_in_image_ = have;
 }
 
 void RayTracer::getBuffer(unsigned char*& buf, int& w, int& h) {

@@ -20,6 +20,8 @@ struct PathTracingOptions {  // what the reference hard-codes in traceImageGPU (
     bool work_queue = true;  // true: betterPathTracing (wavefront); false: traceImageGPU (one thread per pixel)
     unsigned long long seed = 1984;
     int device = 0;
+    std::vector<int> devices;       // two or more GPU ordinals: samples are split across them (one host thread and one
+                                    // context each), sums added on the host in list order; empty: `device` alone
     // long renders (no counterpart in the reference)
     bool device_bvh = false;        // build the BVH on the GPU (cpt_build_scene) instead of on the host; set before loadScene
     int progressive_spp = 0;        // > 0: refresh the image every this many samples and call on_progress
@@ -52,8 +54,10 @@ public:
 
 private:
     void renderGPU(int w, int h, int mode);
+    void renderMultiGPU(int w, int h, const cpt_render_params& p);
     std::unique_ptr<FlatScene> scene_;
     cpt_ctx* ctx_ = nullptr;
+    std::vector<cpt_ctx*> more_ctx_;  // contexts of options.devices[1..]
     bool uploaded_ = false;
     std::vector<unsigned char> buffer_;
     int buffer_width_ = 0, buffer_height_ = 0;

@@ -465,6 +465,31 @@ def test_cli_renders_png_on_gpu(tmp_path, gpu_scene):
     assert np.array_equal(got, want[::-1])  # PNG rows are top-down, the buffer is bottom-up
 
 
+def test_cli_splits_samples_over_several_contexts(tmp_path):
+    """bin/ray --devices a,b: one host thread and one context per listed GPU, each rendering its share of the
+    samples; rehearsed with the same GPU listed three times (7 samples -> 3 + 2 + 2).  The sample set is the
+    single-context one, only the last additions associate differently, so the 8-bit image may differ by one level
+    in a few channels at most."""
+    import os
+    import subprocess
+    from PIL import Image
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "cuda_path_tracer_amd", "bin", "ray")
+    base = [exe, "-g", "-s", "7", "-r", "5", "-w", "96", scene_path("cornell-box2-transmissive")]
+    one, three = str(tmp_path / "one.png"), str(tmp_path / "three.png")
+    r = subprocess.run(base + [one], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(base[:2] + ["--devices", "0,0,0"] + base[2:] + [three], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    a = np.asarray(Image.open(one).convert("RGB")).astype(int)
+    b = np.asarray(Image.open(three).convert("RGB")).astype(int)
+    assert a.shape == b.shape and np.abs(a - b).max() <= 1 and (a != b).mean() < 0.01
+    r = subprocess.run(base[:2] + ["--devices", "0,99"] + base[2:] + [three], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "GPU 99" in (r.stdout + r.stderr)
+    r = subprocess.run(base[:2] + ["--devices", "0,0", "--progressive", "2"] + base[2:] + [three], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+
+
 def test_progressive_and_resumed_renders_are_bit_identical(gpu_scene):
     """cpt_render_progressive: chunked, stopped-and-resumed and single-call renders hold the same
     radiance sums bit for bit and the same image; the progress callback sees every chunk."""
