@@ -125,7 +125,16 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_generate(DScene sc, DParams P, Ra
             atten = dv(0, 0, 0);
         }
         const uint32_t p = (uint32_t)slot;
-        store_ray(out, p, o, d, 1.0, atten, p);
+        if (P.rr) {
+            store_ray(out, p, o, d, 1.0, atten, p);
+        } else {
+            // without roulette a first ray's medium, throughput and slot are constants (1, (1,1,1), its own position):
+            // only the geometry is stored, and the first shade launch (FIRST) does not read the rest
+            cpt_v2d v;
+            v.x = o.x; v.y = o.y; CPT_NT_STORE(out.oxy[p], v);
+            v.x = o.z; v.y = d.x; CPT_NT_STORE(out.ozdx[p], v);
+            v.x = d.y; v.y = d.z; CPT_NT_STORE(out.dyz[p], v);
+        }
         col.cx[slot] = 0.0; col.cy[slot] = 0.0; col.cz[slot] = 0.0;
     }
 }
@@ -413,7 +422,9 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
 
 // ---- shade + compact -------------------------------------------------------------------------
 // reference: the shading half of pathTrace (src/improved_path_tracer.cu:77-215)
-template <bool COUNT>
+// FIRST: the stream is the one k_generate wrote without roulette: geometry only, position = slot, medium 1,
+// throughput (1,1,1).  A slot outside the image holds a ray that leaves the scene, so it ends here as a miss.
+template <bool COUNT, bool FIRST>
 __global__ void __launch_bounds__(CPT_SHADE_BLOCK, 4) k_shade(DScene sc, DParams P, RayStream in, HitBuf hit, RayStream out,
                                                            Radiance col, int batch_s0, int bounce,
                                                            const uint32_t* __restrict__ counter_in, uint32_t* counter_out,
@@ -431,12 +442,18 @@ __global__ void __launch_bounds__(CPT_SHADE_BLOCK, 4) k_shade(DScene sc, DParams
             load_hit(hit, q, t, tri);
             if (COUNT) { segs++; hits += (tri >= 0); }
             if (tri >= 0) {
-                slot = CPT_NT_LOAD(in.slot[q]);
+                slot = FIRST ? q : CPT_NT_LOAD(in.slot[q]);
                 int k = (int)fast_div(slot, P.by_pix_slots), ps = (int)slot - k * P.n_pix_slots;
                 int i, j;
                 slot_to_pixel(P, ps, i, j);
                 uint32_t pixel = (uint32_t)(i + j * P.w), sample = (uint32_t)(batch_s0 + k);
-                load_ray(in, q, s);
+                if (FIRST) {
+                    load_ray_geometry(in, q, s.o, s.d);
+                    s.medium = 1.0;
+                    s.atten = dv(1, 1, 1);
+                } else {
+                    load_ray(in, q, s);
+                }
                 dvec3 emitted;
                 int lobe = choose_lobe(sc, P, pixel, sample, bounce, tri, s.atten, emitted);
                 if (emitted.x != 0.0 || emitted.y != 0.0 || emitted.z != 0.0) {  // adding zero changes nothing: skip the round trip
@@ -655,8 +672,13 @@ void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const 
                   uint32_t* counter_out, long long max_entries, unsigned long long* work) {
     long long b = (max_entries + CPT_SHADE_BLOCK - 1) / CPT_SHADE_BLOCK;
     int g = (int)(b < 1 ? 1 : (b > L.max_blocks ? L.max_blocks : b));
-    if (work) hipLaunchKernelGGL(k_shade<true>, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, in, hit, out, col, batch_s0, bounce, counter_in, counter_out, work);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, in, hit, out, col, batch_s0, bounce, counter_in, counter_out, work);
+    const bool first = bounce == 0 && !P.rr;  // the stream k_generate wrote in its lean form
+#define CPT_SHADE_LAUNCH(COUNT, FIRST)                                                                                      \
+    hipLaunchKernelGGL((k_shade<COUNT, FIRST>), dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, in, hit, out, col, batch_s0, \
+                       bounce, counter_in, counter_out, work)
+    if (work) { if (first) CPT_SHADE_LAUNCH(true, true); else CPT_SHADE_LAUNCH(true, false); }
+    else { if (first) CPT_SHADE_LAUNCH(false, true); else CPT_SHADE_LAUNCH(false, false); }
+#undef CPT_SHADE_LAUNCH
 }
 void launch_resolve(const LaunchCfg& L, const DParams& P, const Radiance& col, int batch_n, double* accum) {
     int g = grid_for(P.n_pix_slots, L.max_blocks);
