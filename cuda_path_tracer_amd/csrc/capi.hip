@@ -59,7 +59,7 @@ struct cpt_ctx {
     std::vector<hipEvent_t> events;
 
     int max_blocks = 0;            // grid cap of the grid-stride kernels
-    long long batch_paths = 1 << 26;  // path slots of one batch of the wavefront pipeline (8.3 GB of streams per batch in flight)
+    long long batch_paths = 1 << 27;  // path slots of one batch of the wavefront pipeline (at most: 208 bytes each, 28 GB per batch in flight)
     int pw_blocks = 0;             // persistent workgroups of the extend kernel (one per CU)
     int pw_chunk = 0;              // rays a persistent wave claims per atomic; 0: chosen from the scene, see chunk_for
     int pw_refill = 12, pw_leaf_go = 32, pw_full_go = 1;
