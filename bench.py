@@ -89,7 +89,9 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="wavefront", choices=["wavefront", "mega"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch-paths", type=int, default=0)
+    ap.add_argument("--batch-paths", type=int, default=1 << 27,
+                    help="path slots per batch; the library's own default (2^25) suits short-lived processes, a long-lived one "
+                         "can afford the larger allocation and gets shorter launch tails (0: library default)")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight at once (library default when 0)")
     ap.add_argument("--device-bvh", action="store_true",
                     help="have the GPU build the BVH (a Morton-order tree) instead of uploading the reference's tree; "
@@ -263,7 +265,7 @@ def main():
         out = {"metric": "Mpaths/s", "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": wl["desc"], "mode": args.mode,
+               "config": {"workload": wl["desc"], "mode": args.mode, "batch_paths": args.batch_paths,
                           "bvh": "built on the GPU (Morton order)" if args.device_bvh else "reference tree (host build)", "paths_per_step": world * paths_per_step_per_gpu,
                           "sharding": "spp range per rank, fp64 radiance reduce to rank 0" if world > 1 else "single GPU"},
                "roofline": roof}

@@ -52,6 +52,7 @@ void usage(const char* prog, const Cli& c) {
               << "  --rr        Russian roulette\n"
               << "  --seed <#>  random seed (default 1984)\n"
               << "  --device <#> GPU ordinal (default 0)\n"
+              << "  --batch <#>  path slots per batch (208 bytes each, two batches in flight; default 2^27 at most)\n"
               << "  --devices <#,#,...>  split the samples over these GPUs (one host thread and context each)\n"
               << "  --device-bvh        build the BVH on the GPU (a Morton-order tree, not the reference's)\n"
               << "  --progressive <#>   rewrite the output image every # samples per pixel\n"
@@ -83,6 +84,7 @@ int main(int argc, char** argv) {
                                 {"device", required_argument, nullptr, 1004}, {"progressive", required_argument, nullptr, 1005},
                                 {"checkpoint", required_argument, nullptr, 1006}, {"metrics", required_argument, nullptr, 1007},
                                 {"device-bvh", no_argument, nullptr, 1008},     {"devices", required_argument, nullptr, 1009},
+                                {"batch", required_argument, nullptr, 1010},
                                 {nullptr, 0, nullptr, 0}};
     int o;
     while ((o = getopt_long(argc, argv, "tr:w:hj:c:gs:", longopts, nullptr)) != -1) {
@@ -111,6 +113,7 @@ int main(int argc, char** argv) {
             case 1006: c.pt.checkpoint = optarg; break;
             case 1007: c.metrics = optarg; break;
             case 1008: c.pt.device_bvh = true; break;
+            case 1010: c.pt.batch_paths = atoll(optarg); break;
             case 1009:
                 c.pt.devices.clear();
                 for (const char* q = optarg; *q;) {

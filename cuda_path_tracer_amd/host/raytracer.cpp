@@ -71,6 +71,7 @@ void RayTracer::renderGPU(int w, int h, int mode) {
     }
     if (!ctx_) {
         if (cpt_create(multi ? options.devices[0] : options.device, &ctx_) != CPT_OK) { error_ = cpt_last_error(nullptr); ctx_ = nullptr; return; }
+        if (options.batch_paths > 0 && cpt_set_option(ctx_, "batch_paths", options.batch_paths) != CPT_OK) { error_ = cpt_last_error(ctx_); return; }
     }
     if (!uploaded_) {
         cpt_scene_desc d = scene_->describe();
@@ -172,6 +173,7 @@ void RayTracer::renderMultiGPU(int w, int h, const cpt_render_params& p) {
     auto work = [&](size_t k) {
         cpt_ctx*& c = k == 0 ? ctx_ : more_ctx_[k - 1];
         if (!c && cpt_create(options.devices[k], &c) != CPT_OK) { errors[k] = cpt_last_error(nullptr); c = nullptr; return; }
+        if (k > 0 && options.batch_paths > 0 && cpt_set_option(c, "batch_paths", options.batch_paths) != CPT_OK) { errors[k] = cpt_last_error(c); return; }
         if (k > 0 && (on_device ? cpt_build_scene(c, &d) : cpt_upload_scene(c, &d)) != CPT_OK) { errors[k] = cpt_last_error(c); return; }
         const int total = p.sample_end - p.sample_begin, base = total / (int)n, extra = total % (int)n;
         cpt_render_params q = p;

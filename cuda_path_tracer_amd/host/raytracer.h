@@ -20,6 +20,7 @@ struct PathTracingOptions {  // what the reference hard-codes in traceImageGPU (
     bool work_queue = true;  // true: betterPathTracing (wavefront); false: traceImageGPU (one thread per pixel)
     unsigned long long seed = 1984;
     int device = 0;
+    long long batch_paths = 0;      // > 0: path slots per batch (cpt_set_option "batch_paths"); 0: the library's default
     std::vector<int> devices;       // two or more GPU ordinals: samples are split across them (one host thread and one
                                     // context each), sums added on the host in list order; empty: `device` alone
     // long renders (no counterpart in the reference)

@@ -158,7 +158,7 @@ def test_sample_ranges_add_up_and_batching_does_not_matter(gpu_scene):
         g.render_into(parts.data_ptr(), g.params(w, h, 0, 5, depth))
         g.render_into(parts.data_ptr(), g.params(w, h, 5, 12, depth))
     finally:
-        g.set_option("batch_paths", 1 << 27)
+        g.set_option("batch_paths", 1 << 25)
     g.synchronize()
     assert np.array_equal(bits(whole.cpu().numpy()), bits(parts.cpu().numpy()))
 
@@ -443,7 +443,7 @@ def test_every_pipeline_variant_gives_the_same_image(gpu_scene):
     finally:
         g.set_option("extend_variant", 1)
         g.set_option("streams", 2)
-        g.set_option("batch_paths", 1 << 27)
+        g.set_option("batch_paths", 1 << 25)
     for im in images[1:]:
         assert np.array_equal(bits(images[0]), bits(im))
 
