@@ -77,7 +77,7 @@ MODE_MEGAKERNEL = 1
 # every symbol include/cpt_amd.h declares
 AMD_SYMBOLS = [
     "cpt_create", "cpt_destroy", "cpt_last_error", "cpt_set_stream", "cpt_set_option", "cpt_set_instrumentation",
-    "cpt_upload_scene", "cpt_build_scene", "cpt_download_tree", "cpt_render", "cpt_tonemap", "cpt_render_image", "cpt_render_progressive", "cpt_synchronize", "cpt_get_stats",
+    "cpt_upload_scene", "cpt_build_scene", "cpt_refit_scene", "cpt_download_tree", "cpt_render", "cpt_tonemap", "cpt_render_image", "cpt_render_progressive", "cpt_synchronize", "cpt_get_stats",
     "cpt_reset_stats", "cpt_extend_rays", "cpt_trace_rays", "cpt_camera_rays", "cpt_path_radiance", "cpt_probe_math", "cpt_probe_rng",
 ]
 # every symbol include/cpt_host.h declares
@@ -106,6 +106,7 @@ def amd():
         L.cpt_set_instrumentation.argtypes = [vp, C.c_int, C.c_int]
         L.cpt_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
         L.cpt_build_scene.argtypes = [vp, C.POINTER(SceneDesc)]
+        L.cpt_refit_scene.argtypes = [vp, C.POINTER(SceneDesc)]
         L.cpt_download_tree.argtypes = [vp, vp, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
         L.cpt_render.argtypes = [vp, C.POINTER(RenderParams), vp]
         L.cpt_tonemap.argtypes = [vp, vp, i32, i32, i32, vp]

@@ -464,6 +464,56 @@ void launch_build_shade(hipStream_t st, const cpt_tri* d_tris, const cpt_tri_nor
     k_build_shade<<<(n_tris + LB_THREADS - 1) / LB_THREADS, LB_THREADS, 0, st>>>(d_tris, d_normals, d_by_material, n_tris, d_out);
 }
 
+// ---- refit: new vertices, same tree ------------------------------------------------------------------------
+
+// Take the geometry, material and flags of the new triangles, keep the tie-break ranks the tree gave the old ones.
+__global__ void k_update_tris(const cpt_tri* __restrict__ fresh, int n, cpt_tri* __restrict__ tris) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    cpt_tri t = fresh[i];
+    t.test_rank = tris[i].test_rank;
+    tris[i] = t;
+}
+
+// Boxes of the records order[begin, end), all of one level: a leaf child's box is its triangle's bounds, an
+// internal child's the union of the two boxes in its record, which an earlier launch (a deeper level) has redone.
+__global__ void k_refit_level(const int* __restrict__ order, int begin, int end, const cpt_tri* __restrict__ tris,
+                              cpt_node* __restrict__ nodes) {
+    for (int i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
+        cpt_node& r = nodes[order[i]];
+        for (int side = 0; side < 2; ++side) {
+            double* dst = side ? r.rbox : r.lbox;
+            const int ref = side ? r.rref : r.lref;
+            if (ref < 0) {
+                Box b = tri_box(tris[~ref]);
+                for (int k = 0; k < 3; ++k) { dst[k] = b.lo[k]; dst[3 + k] = b.hi[k]; }
+            } else {
+                const cpt_node& c = nodes[ref];
+                for (int k = 0; k < 3; ++k) {
+                    dst[k] = fmin(c.lbox[k], c.rbox[k]);
+                    dst[3 + k] = fmax(c.lbox[3 + k], c.rbox[3 + k]);
+                }
+            }
+        }
+    }
+}
+
+void launch_update_tris(hipStream_t st, const cpt_tri* d_fresh, int n_tris, cpt_tri* d_tris) {
+    k_update_tris<<<(n_tris + LB_THREADS - 1) / LB_THREADS, LB_THREADS, 0, st>>>(d_fresh, n_tris, d_tris);
+}
+
+// d_order: record indices sorted by level; level_start[l] .. level_start[l + 1]: the records of level l (host array,
+// n_levels + 1 entries).  Deepest level first.
+void launch_refit(hipStream_t st, const int* d_order, const int* level_start, int n_levels, const cpt_tri* d_tris, cpt_node* d_nodes) {
+    for (int level = n_levels - 1; level >= 0; --level) {
+        const int begin = level_start[level], end = level_start[level + 1];
+        if (end <= begin) continue;
+        int blocks = (end - begin + LB_THREADS - 1) / LB_THREADS;
+        if (blocks > 4096) blocks = 4096;
+        k_refit_level<<<blocks, LB_THREADS, 0, st>>>(d_order, begin, end, d_tris, d_nodes);
+    }
+}
+
 size_t lbvh_work_bytes(int n_tris) { return carve(nullptr, n_tris).bytes; }
 
 // Builds the tree over d_tris[0, n_tris) into d_nodes[0, n_tris - 1) and fills the triangles' test_rank.

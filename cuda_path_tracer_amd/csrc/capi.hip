@@ -411,6 +411,58 @@ int cpt_build_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     return CPT_OK;
 }
 
+int cpt_refit_scene(cpt_ctx* c, const cpt_scene_desc* s) {
+    if (!c || !s) return CPT_EINVAL;
+    if (!c->has_scene) return fail(c, CPT_ENOSCENE, "cpt_refit_scene: no scene uploaded");
+    int rc = validate_triangles(c, s);
+    if (rc != CPT_OK) return rc;
+    if (s->n_tris != c->sc.n_tris) return fail(c, CPT_EINVAL, "refit needs the same %d triangles, got %d", c->sc.n_tris, s->n_tris);
+    const int n = s->n_tris, m = c->sc.n_nodes;
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(s->tris[i].a[k]) || !std::isfinite(s->tris[i].b[k]) || !std::isfinite(s->tris[i].c[k]))
+                return fail(c, CPT_EINVAL, "triangle %d: vertex is not finite", i);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // levels of the records of the tree in place (children are stored after their parents, so one forward pass
+    // finds every depth), then the records listed level by level
+    std::vector<int> order((size_t)m), level_start;
+    if (m > 0) {
+        std::vector<cpt_node> nodes((size_t)m);
+        HIP_TRY(c, hipMemcpy(nodes.data(), c->d_nodes, sizeof(cpt_node) * (size_t)m, hipMemcpyDeviceToHost));
+        std::vector<int> level((size_t)m, 0);
+        int n_levels = 1;
+        for (int k = 0; k < m; ++k) {
+            const int refs[2] = {nodes[(size_t)k].lref, nodes[(size_t)k].rref};
+            for (int q = 0; q < 2; ++q)
+                if (refs[q] >= 0) { level[(size_t)refs[q]] = level[(size_t)k] + 1; n_levels = std::max(n_levels, level[(size_t)k] + 2); }
+        }
+        level_start.assign((size_t)n_levels + 1, 0);
+        for (int k = 0; k < m; ++k) level_start[(size_t)level[(size_t)k] + 1]++;
+        for (int l = 0; l < n_levels; ++l) level_start[(size_t)l + 1] += level_start[(size_t)l];
+        std::vector<int> at(level_start.begin(), level_start.end() - 1);
+        for (int k = 0; k < m; ++k) order[(size_t)at[(size_t)level[(size_t)k]]++] = k;
+    }
+    void *d_fresh = nullptr, *d_order = nullptr;
+    hipError_t e = hipMalloc(&d_fresh, sizeof(cpt_tri) * (size_t)n);
+    if (e == hipSuccess && m > 0) e = hipMalloc(&d_order, sizeof(int) * (size_t)m);
+    if (e == hipSuccess) e = hipMemcpy(d_fresh, s->tris, sizeof(cpt_tri) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && m > 0) e = hipMemcpy(d_order, order.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_update_tris(c->stream, (const cpt_tri*)d_fresh, n, (cpt_tri*)c->d_tris);
+        if (m > 0) launch_refit(c->stream, (const int*)d_order, level_start.data(), (int)level_start.size() - 1, (const cpt_tri*)c->d_tris, (cpt_node*)c->d_nodes);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_fresh);
+    (void)hipFree(d_order);
+    if (e != hipSuccess) return fail(c, CPT_EHIP, "refit: %s", hipGetErrorString(e));
+    rc = upload_shading(c, s);
+    if (rc != CPT_OK) return rc;
+    c->sc.cam = s->camera;
+    return CPT_OK;
+}
+
 int cpt_download_tree(cpt_ctx* c, cpt_node* h_nodes, int32_t node_capacity, uint32_t* h_test_rank, int32_t tri_capacity,
                       int32_t* n_nodes, int32_t* height) {
     if (!c) return CPT_EINVAL;

@@ -165,6 +165,8 @@ void launch_probe_rng(const LaunchCfg& L, const uint32_t c[4], const uint32_t k[
 // Device-side scene preparation (bvh_device.hip).
 void launch_build_shade(hipStream_t st, const cpt_tri* d_tris, const cpt_tri_normals* d_normals, const ShadeRec* d_by_material,
                         int n_tris, ShadeRec* d_out);
+void launch_update_tris(hipStream_t st, const cpt_tri* d_fresh, int n_tris, cpt_tri* d_tris);
+void launch_refit(hipStream_t st, const int* d_order, const int* level_start, int n_levels, const cpt_tri* d_tris, cpt_node* d_nodes);
 size_t lbvh_work_bytes(int n_tris);
 hipError_t launch_lbvh_build(hipStream_t st, cpt_tri* d_tris, int n_tris, cpt_node* d_nodes, void* d_work, int morton_bits,
                              int* h_height);

@@ -77,6 +77,11 @@ class Renderer:
         self._check(self._L.cpt_build_scene(self._h, C.byref(host_scene.desc)), "cpt_build_scene")
         self._scene = host_scene
 
+    def refit(self, host_scene):
+        """Same triangles with new vertices: recompute the boxes of the tree on the GPU, keep its topology."""
+        self._check(self._L.cpt_refit_scene(self._h, C.byref(host_scene.desc)), "cpt_refit_scene")
+        self._scene = host_scene
+
     def download_tree(self):
         """(nodes, test_rank, height) of the scene on the GPU: node records as a structured array of _capi.Node."""
         n, h = C.c_int32(0), C.c_int32(0)

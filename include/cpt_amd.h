@@ -178,6 +178,13 @@ int cpt_upload_scene(cpt_ctx* ctx, const cpt_scene_desc* scene);
  * CPT_ELIMIT if even that fails.  Synchronous. */
 int cpt_build_scene(cpt_ctx* ctx, const cpt_scene_desc* scene);
 
+/* New vertices (and normals, materials, camera) for the scene on the GPU, same triangles in the same order, same
+ * tree: every box of the tree in place is recomputed on the device, bottom-up, from the new triangle bounds;
+ * topology, node numbering and tie-break ranks stay.  For geometry that moves a little between renders, where a
+ * rebuild is not worth it; the tree stays correct for any motion, only less tight.  `scene->nodes` is ignored.
+ * No reference counterpart (the reference rebuilds and re-uploads everything per process).  Synchronous. */
+int cpt_refit_scene(cpt_ctx* ctx, const cpt_scene_desc* scene);
+
 /* Read back the node records (and, if h_test_rank is not NULL, every triangle's tie-break rank) of the
  * scene on the GPU, however it got there.  h_nodes may be NULL to query *n_nodes / *height only.
  * No reference counterpart: lets a host inspect, cache or cross-check a device-built tree. */

@@ -1,6 +1,6 @@
 // The C ABI of the GPU library, driven from C++ with the library's HOST code built under AddressSanitizer and
 // UndefinedBehaviorSanitizer (device code cannot be sanitized on this pool): create, upload, render, tonemap,
-// progressive render, explicit rays, device-side build, tree download, malformed input, destroy.
+// progressive render, explicit rays, device-side build, refit, tree download, malformed input, destroy.
 // Built by tests/sanitize/build_capi_driver.sh here, run on the GPU by tests/test_gpu_sanitized_capi.py.
 #include <cmath>
 #include <cstdio>
@@ -64,6 +64,9 @@ int main(int argc, char** argv) {
             CHECK(cpt_trace_rays(ctx, n, o.data(), dir.data(), tri2.data(), t2.data(), nrm.data(), vh.data(), counts.data(), nullptr, 0));
             if (tri != tri2 || std::memcmp(t.data(), t2.data(), sizeof(double) * n) != 0) { std::printf("hooks disagree\n"); return 1; }
         }
+        CHECK(cpt_refit_scene(ctx, &d));  // same vertices: the boxes must come out as they were
+        CHECK(cpt_extend_rays(ctx, n, o.data(), dir.data(), tri2.data(), t2.data()));
+        if (tri != tri2 || std::memcmp(t.data(), t2.data(), sizeof(double) * n) != 0) { std::printf("refit changed the hits\n"); return 1; }
         int32_t n_nodes = 0, height = 0;
         CHECK(cpt_download_tree(ctx, nullptr, 0, nullptr, 0, &n_nodes, &height));
         std::vector<cpt_node> nodes((size_t)(n_nodes > 0 ? n_nodes : 1));

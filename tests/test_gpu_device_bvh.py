@@ -308,3 +308,49 @@ def test_large_triangle_soup(gpu):
     assert ((tri >= 0) & (t <= dist * (1 + 1e-9))).all()
     got = gpu.trace_rays(o, d)
     assert np.array_equal(got["prim"], tri) and np.array_equal(bits(got["t"]), bits(t))
+
+
+def test_refit_keeps_the_tree_and_redoes_its_boxes(gpu, oracle, tmp_path):
+    """cpt_refit_scene: the same triangles with moved vertices.  Topology, numbering and ranks stay, every box
+    becomes the exact bound of the moved geometry below it, and the oracle walking that tree over the moved
+    triangles agrees bit for bit -- for a tree that came from the host and for one built on the device."""
+    import torch
+    from cuda_path_tracer_amd import CptError, HostScene, Renderer
+    rng = np.random.default_rng(21)
+    n = 400
+    centre = rng.uniform(0, 1, (n, 1, 3))
+    before = centre + rng.normal(size=(n, 3, 3)) * 0.03
+    after = before + 0.05 * np.sin(7.0 * before[:, :, [1, 2, 0]]) + rng.normal(size=(n, 1, 3)) * 0.01  # bend and jiggle
+    text_a, text_b = _mesh_text(list(before)), _mesh_text(list(after))
+    hs_a, hs_b = HostScene(text=text_a), HostScene(text=text_b)
+    assert hs_a.n_tris == hs_b.n_tris == n
+    path_b = tmp_path / "after.ray"
+    path_b.write_text(text_b)
+    for place in (gpu.upload, gpu.build):
+        place(hs_a)
+        nodes_a, rank_a, height_a = gpu.download_tree()
+        gpu.refit(hs_b)
+        nodes_b, rank_b, height_b = gpu.download_tree()
+        for key in ("lref", "rref", "lid", "rid", "self_id"):
+            assert np.array_equal(nodes_a[key], nodes_b[key])
+        assert np.array_equal(rank_a, rank_b) and height_a == height_b
+        assert not np.array_equal(nodes_a["lbox"], nodes_b["lbox"])
+        check_structure(nodes_b, rank_b, height_b, hs_b.tris())
+        orc = oracle.OracleScene(str(path_b))
+        boxes, topo = tree_table(nodes_b, n)
+        orc.set_tree(boxes, topo)
+        compare_with_oracle_on_same_tree(gpu, orc, boxes, 4000, 8)
+        w = h = 40
+        acc = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+        gpu.render_into(acc.data_ptr(), gpu.params(w, h, 0, 3, 3))
+        gpu.synchronize()
+        want, _ = orc.render(w, h, 0, 3, 3)
+        assert np.allclose(acc.cpu().numpy(), want, rtol=1e-9, atol=1e-12)
+    with pytest.raises(CptError):
+        gpu.refit(HostScene(text=_mesh_text(list(after[:-1]))))  # another triangle count
+    fresh = Renderer(0)
+    try:
+        with pytest.raises(CptError):
+            fresh.refit(hs_b)  # nothing to refit
+    finally:
+        fresh.close()
