@@ -43,7 +43,7 @@ struct cpt_ctx {
         RayStream R[2]{};
         HitBuf H{};
         Radiance C{};
-        uint32_t* d_counters = nullptr;    // CPT_MAX_DEPTH + 2 stream lengths
+        uint32_t* d_counters = nullptr;    // per bounce the lengths of the stream's segments (CPT_PW_CURSOR_WORDS words)
         uint32_t* d_cursors = nullptr;     // per bounce CPT_PW_CURSOR_WORDS claim counters of the persistent extend kernel
         uint32_t* d_spill = nullptr;       // stack overflow columns of the persistent-wave extend kernel
         int spill_blocks = 0;
@@ -122,7 +122,7 @@ int cpt_create(int device, cpt_ctx** out) {
     if (e != hipSuccess) { delete c; return fail(nullptr, CPT_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
     for (int k = 0; k < CPT_MAX_LANES && e == hipSuccess; ++k) {
-        e = hipMalloc((void**)&c->lanes[k].d_counters, (CPT_MAX_DEPTH + 2) * sizeof(uint32_t));
+        e = hipMalloc((void**)&c->lanes[k].d_counters, (size_t)(CPT_MAX_DEPTH + 2) * CPT_PW_CURSOR_WORDS * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void**)&c->lanes[k].d_cursors, (size_t)(CPT_MAX_DEPTH + 2) * CPT_PW_CURSOR_WORDS * sizeof(uint32_t));
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->lanes[k].resolved, hipEventDisableTiming);
         if (e == hipSuccess && k > 0) e = hipStreamCreateWithFlags(&c->lanes[k].own_stream, hipStreamNonBlocking);
@@ -620,7 +620,7 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
     for (int k = 0; k < n_lanes; ++k) {
         rc = ensure_spill(c, c->lanes[k], lane_stream(c, k));
         if (rc) return rc;
-        rc = ensure_paths(c, c->lanes[k], lane_stream(c, k), (size_t)batch * (size_t)per_sample);
+        rc = ensure_paths(c, c->lanes[k], lane_stream(c, k), cpt_stream_positions((size_t)batch * (size_t)per_sample));
         if (rc) return rc;
     }
     const size_t n_ev = 2 * (size_t)(P.depth + 1) + 3;
@@ -638,18 +638,20 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
         long long slots = (long long)bn * per_sample;
         size_t ev = 0;
         uint32_t* cursors = ln.d_cursors;
-        HIP_TRY(c, hipMemsetAsync(ln.d_counters, 0, (size_t)(P.depth + 2) * sizeof(uint32_t), L.stream));
+        const uint32_t cap = cpt_segment_cap((size_t)slots);
+        HIP_TRY(c, hipMemsetAsync(ln.d_counters, 0, (size_t)(P.depth + 2) * CPT_PW_CURSOR_WORDS * sizeof(uint32_t), L.stream));
         if (c->extend_variant >= 1) HIP_TRY(c, hipMemsetAsync(cursors, 0, (size_t)(P.depth + 1) * CPT_PW_CURSOR_WORDS * sizeof(uint32_t), L.stream));
         if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
-        HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)ln.d_counters, (int)slots, 1, L.stream));
+        launch_dense_counts(L, ln.d_counters, (uint32_t)slots, cap);  // the first rays sit at positions 0 .. slots-1
         launch_generate(L, c->sc, P, ln.R[0], ln.C, bs, bn);
         if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
         for (int b = 0; b <= P.depth; ++b) {
             const RayStream& in = ln.R[b & 1];
-            if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, ln.d_counters + b, cursors + (size_t)b * CPT_PW_CURSOR_WORDS, ln.d_spill, work);
-            else launch_extend(L, c->sc, in, ln.H, ln.d_counters + b, slots, work);
+            uint32_t* count_in = ln.d_counters + (size_t)b * CPT_PW_CURSOR_WORDS;
+            if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, count_in, cap, cursors + (size_t)b * CPT_PW_CURSOR_WORDS, ln.d_spill, work);
+            else launch_extend(L, c->sc, in, ln.H, count_in, cap, slots, work);
             if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
-            launch_shade(L, c->sc, P, in, ln.H, ln.R[(b + 1) & 1], ln.C, bs, b, ln.d_counters + b, ln.d_counters + b + 1, slots, work);
+            launch_shade(L, c->sc, P, in, ln.H, ln.R[(b + 1) & 1], ln.C, bs, b, count_in, count_in + CPT_PW_CURSOR_WORDS, cap, slots, work);
             if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
         }
         // a pixel's samples are added in sample order: this batch's resolve follows the previous batch's
@@ -825,7 +827,7 @@ int cpt_extend_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d,
     cpt_ctx::Lane& ln = c->lanes[0];
     int rc = ensure_spill(c, ln, c->stream);
     if (rc) return rc;
-    rc = ensure_paths(c, ln, c->stream, (size_t)n);
+    rc = ensure_paths(c, ln, c->stream, cpt_stream_positions((size_t)n));
     if (rc) return rc;
     const size_t N = (size_t)n;
     std::vector<double> packed(6 * N);  // the stream keeps components in pairs: (ox, oy) | (oz, dx) | (dy, dz)
@@ -837,12 +839,13 @@ int cpt_extend_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d,
     cpt_v2d* dst[3] = {in.oxy, in.ozdx, in.dyz};
     for (int k = 0; k < 3; ++k) HIP_TRY(c, hipMemcpyAsync(dst[k], packed.data() + (size_t)k * 2 * N, 2 * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
     uint32_t* cursors = ln.d_cursors;
-    HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)ln.d_counters, n, 1, c->stream));
     HIP_TRY(c, hipMemsetAsync(cursors, 0, CPT_PW_CURSOR_WORDS * sizeof(uint32_t), c->stream));
+    const uint32_t cap = cpt_segment_cap((size_t)n);
     LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
     unsigned long long* work = c->count_work ? c->d_work : nullptr;
-    if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, ln.d_counters, cursors, ln.d_spill, work);
-    else launch_extend(L, c->sc, in, ln.H, ln.d_counters, (long long)n, work);
+    launch_dense_counts(L, ln.d_counters, (uint32_t)n, cap);
+    if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, ln.d_counters, cap, cursors, ln.d_spill, work);
+    else launch_extend(L, c->sc, in, ln.H, ln.d_counters, cap, (long long)n, work);
     HIP_TRY(c, hipGetLastError());
     c->stats.launches_extend++;
     std::vector<HitRec> recs(N);

@@ -139,16 +139,38 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_generate(DScene sc, DParams P, Ra
     }
 }
 
+// ---- segmented streams -------------------------------------------------------------------------
+// A stream is CPT_PW_SEGMENTS independent runs: segment s holds its rays at positions [s * cap, s * cap + count[s]),
+// count[s] kept in word s * 32 of the stream's counter block (a 128-byte line each).  Shade compacts the survivors
+// of segment s into segment s of the other stream, so the workgroups of a launch spread their output claims over
+// CPT_PW_SEGMENTS counters instead of one: a single address takes on the order of 10^8 atomics per second, which
+// 156 000 workgroup claims per launch of 40 M rays ran into.
+// A dense run of n rays at positions 0 .. n-1 (first rays, caller-supplied rays) is the same thing with every
+// segment but the last ones full.
+__global__ void k_dense_counts(uint32_t* __restrict__ counts, uint32_t n, uint32_t cap) {
+    const uint32_t s = threadIdx.x;
+    if (s < CPT_PW_SEGMENTS) {
+        const unsigned long long lo = (unsigned long long)s * cap;
+        counts[s * 32u] = lo >= n ? 0u : (n - lo < cap ? (uint32_t)(n - lo) : cap);
+    }
+}
+
 // ---- extend --------------------------------------------------------------------------------
 // Closest hit for every ray of the stream, one ray per thread.
 // reference: the intersection half of pathTrace (src/improved_path_tracer.cu:56-76)
 template <bool COUNT>
 __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, HitBuf hit,
-                                                      const uint32_t* __restrict__ counter, unsigned long long* work) {
+                                                      const uint32_t* __restrict__ counter, uint32_t cap, unsigned long long* work) {
     CPT_DECLARE_STACK
-    uint32_t n = *counter;
+    __shared__ uint32_t s_count[CPT_PW_SEGMENTS];
+    if (threadIdx.x < CPT_PW_SEGMENTS) s_count[threadIdx.x] = counter[threadIdx.x * 32u];
+    __syncthreads();
     unsigned long long steps = 0, tris = 0;
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+    const unsigned long long span = (unsigned long long)cap * CPT_PW_SEGMENTS;
+    for (unsigned long long x = blockIdx.x * blockDim.x + threadIdx.x; x < span; x += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t seg = (uint32_t)(x / cap);
+        if ((uint32_t)(x - (unsigned long long)seg * cap) >= s_count[seg]) continue;
+        const uint32_t q = (uint32_t)x;
         dvec3 o, d;
         load_ray_geometry(in, q, o, d);
         double t;
@@ -235,14 +257,17 @@ __device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, cons
 // them; the only loads left are the rays.
 template <bool COUNT, bool CULL, bool RESIDENT>
 __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStream in, HitBuf hit,
-                                                              const uint32_t* __restrict__ counter, uint32_t* cursor,
+                                                              const uint32_t* __restrict__ counter, uint32_t* cursor, uint32_t cap,
                                                               uint32_t chunk, uint32_t refill_at, uint32_t leaf_go, uint32_t full_go, uint32_t* spill, unsigned long long* work) {
     __shared__ __attribute__((aligned(128))) unsigned char s_cache[CPT_PW_CACHE_RECORDS * 128];
     __shared__ uint32_t s_nodes[CPT_PW_WAVES][CPT_PW_STACK_LDS][CPT_WAVE];
     __shared__ uint32_t s_leaves[CPT_PW_WAVES][CPT_PW_LEAF_CAP][CPT_WAVE];
     const uint32_t lane = threadIdx.x & (CPT_WAVE - 1), wave = threadIdx.x / CPT_WAVE;
     const uint64_t lanes_below = (1ull << lane) - 1ull;
-    const uint32_t n = *counter;
+    // lengths of the stream's segments, one per lane of every wave (lanes beyond the segments hold 0)
+    const uint32_t my_count = lane < CPT_PW_SEGMENTS ? counter[lane * 32u] : 0u;
+    uint32_t n = my_count;
+    for (int off = 32; off >= 1; off >>= 1) n += __shfl_xor(n, off);
     // A wave's last chunk is the tail of the launch (its lanes finish one by one while the other waves have
     // nothing left), so a short stream is handed out in smaller chunks: at least eight claims per wave.
     {
@@ -286,9 +311,8 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
         uint64_t idle = __ballot(!has_ray);
         if (!drained && (uint32_t)__popcll(idle) >= refill_at) {
             while (chunk_pos == chunk_end && !drained) {  // claim the next chunk of this wave's current segment
-                const uint32_t seg_lo = (uint32_t)((uint64_t)n * seg / CPT_PW_SEGMENTS);
-                const uint32_t seg_hi = (uint32_t)((uint64_t)n * (seg + 1) / CPT_PW_SEGMENTS);
-                const uint32_t seg_size = seg_hi - seg_lo, size = chunk;
+                const uint32_t seg_size = (uint32_t)__builtin_amdgcn_readlane((int)my_count, (int)seg), size = chunk;
+                const uint32_t seg_lo = seg * cap, seg_hi = seg_lo + seg_size;
                 uint32_t off = 0;
                 if (lane == 0) off = atomicAdd(cursor + seg * 32u, size);
                 off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
@@ -430,16 +454,27 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
 template <bool COUNT, bool FIRST>
 __global__ void __launch_bounds__(CPT_SHADE_BLOCK, 5) k_shade(DScene sc, DParams P, RayStream in, HitBuf hit, RayStream out,
                                                            Radiance col, int batch_s0, int bounce,
-                                                           const uint32_t* __restrict__ counter_in, uint32_t* counter_out,
+                                                           const uint32_t* __restrict__ counter_in, uint32_t* counter_out, uint32_t cap,
                                                            unsigned long long* work) {
-    uint32_t n = *counter_in;
-    uint32_t n_round = (n + CPT_SHADE_BLOCK - 1) / CPT_SHADE_BLOCK * CPT_SHADE_BLOCK;  // whole workgroups reach block_claim together
+    __shared__ uint32_t s_count[CPT_PW_SEGMENTS];
+    if (threadIdx.x < CPT_PW_SEGMENTS) s_count[threadIdx.x] = counter_in[threadIdx.x * 32u];
+    __syncthreads();
+    uint32_t longest = 0;
+    for (int k = 0; k < CPT_PW_SEGMENTS; ++k) longest = s_count[k] > longest ? s_count[k] : longest;
+    // work items: (segment, 256-ray piece of it), enumerated piece-major so that the workgroups running at any one
+    // time are working on -- and claiming output in -- all the segments
+    const uint32_t pieces = (longest + CPT_SHADE_BLOCK - 1) / CPT_SHADE_BLOCK;
     unsigned long long hits = 0, segs = 0;
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_round; q += gridDim.x * blockDim.x) {
+    for (uint32_t item = blockIdx.x; item < pieces * CPT_PW_SEGMENTS; item += gridDim.x) {
+        const uint32_t seg = item % CPT_PW_SEGMENTS, piece = item / CPT_PW_SEGMENTS;
+        const uint32_t n_seg = s_count[seg];
+        if (piece * CPT_SHADE_BLOCK >= n_seg) continue;  // the whole workgroup: nothing reaches block_claim
+        const uint32_t off = piece * CPT_SHADE_BLOCK + threadIdx.x;
+        const uint32_t q = seg * cap + off;
         bool go = false;
         uint32_t slot = 0;
         PathRegs s;
-        if (q < n) {
+        if (off < n_seg) {
             int tri;
             double t;
             load_hit(hit, q, t, tri);
@@ -468,8 +503,8 @@ __global__ void __launch_bounds__(CPT_SHADE_BLOCK, 5) k_shade(DScene sc, DParams
                 }
             }
         }
-        uint32_t p = block_claim(counter_out, go);
-        if (go) store_ray(out, p, s, slot);
+        uint32_t p = block_claim(counter_out + seg * 32u, go);
+        if (go) store_ray(out, seg * cap + p, s, slot);
     }
     if (COUNT) {
         if (segs) atomicAdd(&work[1], segs);
@@ -643,18 +678,21 @@ void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, con
     int g = grid_for((long long)batch_n * P.n_pix_slots, L.max_blocks);
     hipLaunchKernelGGL(k_generate, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, out, col, batch_s0, batch_n);
 }
+void launch_dense_counts(const LaunchCfg& L, uint32_t* counts, uint32_t n, uint32_t cap) {
+    hipLaunchKernelGGL(k_dense_counts, dim3(1), dim3(64), 0, L.stream, counts, n, cap);
+}
 void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
-                   long long max_entries, unsigned long long* work) {
+                   uint32_t cap, long long max_entries, unsigned long long* work) {
     int g = grid_for(max_entries, L.max_blocks);
-    if (work) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, in, hit, counter, work);
-    else hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, in, hit, counter, work);
+    if (work) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, in, hit, counter, cap, work);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, in, hit, counter, cap, work);
 }
 void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
-                      uint32_t* cursor, uint32_t* spill, unsigned long long* work) {
+                      uint32_t cap, uint32_t* cursor, uint32_t* spill, unsigned long long* work) {
     int g = L.pw_blocks;
 #define CPT_PW_LAUNCH(COUNT, CULL, RES)                                                                                  \
     hipLaunchKernelGGL((k_extend_pw<COUNT, CULL, RES>), dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, \
-                       cursor, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go,                       \
+                       cursor, cap, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go,                       \
                        (uint32_t)L.pw_full_go, spill, work)
     const bool resident = L.pw_resident != 0;
     const int which = (work ? 4 : 0) | (L.pw_cull ? 2 : 0) | (resident ? 1 : 0);
@@ -672,13 +710,13 @@ void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in,
 }
 void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& in, const HitBuf& hit,
                   const RayStream& out, const Radiance& col, int batch_s0, int bounce, const uint32_t* counter_in,
-                  uint32_t* counter_out, long long max_entries, unsigned long long* work) {
+                  uint32_t* counter_out, uint32_t cap, long long max_entries, unsigned long long* work) {
     long long b = (max_entries + CPT_SHADE_BLOCK - 1) / CPT_SHADE_BLOCK;
     int g = (int)(b < 1 ? 1 : (b > L.max_blocks ? L.max_blocks : b));
     const bool first = bounce == 0 && !P.rr;  // the stream k_generate wrote in its lean form
 #define CPT_SHADE_LAUNCH(COUNT, FIRST)                                                                                      \
     hipLaunchKernelGGL((k_shade<COUNT, FIRST>), dim3(g), dim3(CPT_SHADE_BLOCK), 0, L.stream, sc, P, in, hit, out, col, batch_s0, \
-                       bounce, counter_in, counter_out, work)
+                       bounce, counter_in, counter_out, cap, work)
     if (work) { if (first) CPT_SHADE_LAUNCH(true, true); else CPT_SHADE_LAUNCH(true, false); }
     else { if (first) CPT_SHADE_LAUNCH(false, true); else CPT_SHADE_LAUNCH(false, false); }
 #undef CPT_SHADE_LAUNCH

@@ -127,7 +127,10 @@ struct Radiance {           // radiance gathered per path, indexed by slot; touc
 // of its own in its own 128-byte line; a wave works through its home segment and then helps with the
 // others.
 #define CPT_PW_SEGMENTS 16
-#define CPT_PW_CURSOR_WORDS (CPT_PW_SEGMENTS * 32)  // u32 words of claim counters per bounce
+#define CPT_PW_CURSOR_WORDS (CPT_PW_SEGMENTS * 32)  // u32 words of claim counters per bounce; a stream's segment lengths take as many
+// Positions a stream of n rays needs, and the capacity of one of its CPT_PW_SEGMENTS segments.
+inline uint32_t cpt_segment_cap(size_t n) { return (uint32_t)(((n + CPT_PW_SEGMENTS - 1) / CPT_PW_SEGMENTS + 63) / 64 * 64); }
+inline size_t cpt_stream_positions(size_t n) { return (size_t)cpt_segment_cap(n) * CPT_PW_SEGMENTS; }
 #define CPT_PW_CACHE_RECORDS_HOST 512  // records of the scene the persistent extend kernel keeps in LDS
 #define CPT_PW_THREADS_HOST 1024
 
@@ -145,13 +148,14 @@ struct LaunchCfg {
 
 void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& out, const Radiance& col,
                      int batch_s0, int batch_n);
+void launch_dense_counts(const LaunchCfg& L, uint32_t* counts, uint32_t n, uint32_t cap);
 void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
-                   long long max_entries, unsigned long long* work);
+                   uint32_t cap, long long max_entries, unsigned long long* work);
 void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
-                      uint32_t* cursor, uint32_t* spill, unsigned long long* work);
+                      uint32_t cap, uint32_t* cursor, uint32_t* spill, unsigned long long* work);
 void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& in, const HitBuf& hit,
                   const RayStream& out, const Radiance& col, int batch_s0, int bounce, const uint32_t* counter_in,
-                  uint32_t* counter_out, long long max_entries, unsigned long long* work);
+                  uint32_t* counter_out, uint32_t cap, long long max_entries, unsigned long long* work);
 void launch_resolve(const LaunchCfg& L, const DParams& P, const Radiance& col, int batch_n, double* accum);
 void launch_megakernel(const LaunchCfg& L, const DScene& sc, const DParams& P, double* accum, unsigned long long* work);
 void launch_tonemap(const LaunchCfg& L, const double* accum, int n_values, int spp, uint8_t* rgb);
