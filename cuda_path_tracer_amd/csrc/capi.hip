@@ -161,7 +161,14 @@ const char* cpt_last_error(const cpt_ctx* c) { return c ? c->err.c_str() : g_cre
 
 int cpt_set_stream(cpt_ctx* c, void* s) {
     if (!c) return CPT_EINVAL;
-    c->stream = s == CPT_OWN_STREAM ? c->own_stream : (hipStream_t)s;
+    hipStream_t next = s == CPT_OWN_STREAM ? c->own_stream : (hipStream_t)s;
+    if (next == c->stream) return CPT_OK;
+    // The context's buffers (lane 0's streams and counters, the scene arrays) are ordered by the stream they were
+    // last used on only: work queued on the new stream must not overtake what is still running on the old one.
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(next, c->ev_fork, 0));
+    c->stream = next;
     return CPT_OK;
 }
 
@@ -516,9 +523,18 @@ static int ensure_spill(cpt_ctx* c, cpt_ctx::Lane& l, hipStream_t st) {
     return CPT_OK;
 }
 
+// One image-size rule for every entry point that takes a width and a height: at most 2^28 pixels, also counted in
+// whole 8x8 tiles (what path slots enumerate, and what fast_div is exact for).
+static int check_image_size(cpt_ctx* c, int w, int h) {
+    if (w < 1 || h < 1) return fail(c, CPT_EINVAL, "bad image size %dx%d", w, h);
+    if ((long long)w * h > (1ll << 28) || (long long)((w + 7) / 8) * ((h + 7) / 8) * 64 > (1ll << 28))
+        return fail(c, CPT_ELIMIT, "image %dx%d too large: at most 2^28 pixels", w, h);
+    return CPT_OK;
+}
+
 static int make_params(cpt_ctx* c, const cpt_render_params* p, DParams& P) {
-    if (p->width < 1 || p->height < 1) return fail(c, CPT_EINVAL, "bad image size %dx%d", p->width, p->height);
-    if ((long long)p->width * p->height > (1ll << 28)) return fail(c, CPT_ELIMIT, "image too large");
+    int size_rc = check_image_size(c, p->width, p->height);
+    if (size_rc != CPT_OK) return size_rc;
     if (p->sample_begin < 0 || p->sample_end < p->sample_begin) return fail(c, CPT_EINVAL, "bad sample range [%d, %d)", p->sample_begin, p->sample_end);
     if (p->depth < 0 || p->depth > CPT_MAX_DEPTH) return fail(c, CPT_EINVAL, "depth %d not in [0, %d]", p->depth, CPT_MAX_DEPTH);
     if (p->mode != CPT_MODE_WAVEFRONT && p->mode != CPT_MODE_MEGAKERNEL) return fail(c, CPT_EINVAL, "unknown mode %d", p->mode);
@@ -527,7 +543,6 @@ static int make_params(cpt_ctx* c, const cpt_render_params* p, DParams& P) {
     P.seed_lo = (uint32_t)p->seed; P.seed_hi = (uint32_t)(p->seed >> 32);
     P.focal_distance = p->focal_distance; P.aperture = p->aperture;
     P.tiles_x = (p->width + 7) / 8; P.tiles_y = (p->height + 7) / 8;
-    if ((long long)P.tiles_x * P.tiles_y * 64 > (1ll << 28)) return fail(c, CPT_ELIMIT, "image too large");  // also what fast_div is exact for
     const int n_tiles = P.tiles_x * P.tiles_y;
     if (p->tile_count < 0 || p->tile_begin < 0 || (p->tile_count == 0 && p->tile_begin != 0) ||
         (long long)p->tile_begin + p->tile_count > n_tiles)
@@ -700,7 +715,11 @@ int cpt_tonemap(cpt_ctx* c, const double* d_accum, int32_t w, int32_t h, int32_t
 int cpt_render_image(cpt_ctx* c, const cpt_render_params* p, uint8_t* h_rgb) {
     if (!c || !p || !h_rgb) return c ? fail(c, CPT_EINVAL, "cpt_render_image: NULL argument") : CPT_EINVAL;
     if (p->sample_end <= p->sample_begin) return fail(c, CPT_EINVAL, "cpt_render_image: empty sample range");
-    if (p->width < 1 || p->height < 1) return fail(c, CPT_EINVAL, "bad image size");
+    {   // every argument check before any buffer is allocated
+        DParams P;
+        int prc = make_params(c, p, P);
+        if (prc != CPT_OK) return prc;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     size_t n = (size_t)p->width * p->height * 3;
     double* d_accum = nullptr;
@@ -736,7 +755,11 @@ int cpt_render_progressive(cpt_ctx* c, const cpt_render_params* p, int32_t chunk
     if (samples_done) *samples_done = 0;
     if (!c || !p || !h_rgb) return c ? fail(c, CPT_EINVAL, "cpt_render_progressive: NULL argument") : CPT_EINVAL;
     if (p->sample_end <= p->sample_begin) return fail(c, CPT_EINVAL, "cpt_render_progressive: empty sample range");
-    if (p->width < 1 || p->height < 1) return fail(c, CPT_EINVAL, "bad image size");
+    {   // every argument check before any buffer is allocated
+        DParams P;
+        int prc = make_params(c, p, P);
+        if (prc != CPT_OK) return prc;
+    }
     if (chunk_spp < 1) return fail(c, CPT_EINVAL, "cpt_render_progressive: chunk_spp must be >= 1");
     if (accum_samples < 0 || (accum_samples > 0 && !h_accum)) return fail(c, CPT_EINVAL, "cpt_render_progressive: accum_samples without h_accum");
     HIP_TRY(c, hipSetDevice(c->device));

@@ -580,9 +580,9 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_megakernel(DScene sc, DParams P, 
 
 // ---- tonemap -----------------------------------------------------------------------------------
 // reference: src/path_tracer.cu:436-443
-__global__ void __launch_bounds__(CPT_BLOCK) k_tonemap(const double* __restrict__ accum, int n_values, int spp,
+__global__ void __launch_bounds__(CPT_BLOCK) k_tonemap(const double* __restrict__ accum, long long n_values, int spp,
                                                        uint8_t* __restrict__ rgb) {
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_values; k += gridDim.x * blockDim.x) {
+    for (long long k = blockIdx.x * blockDim.x + threadIdx.x; k < n_values; k += (long long)gridDim.x * blockDim.x) {
         double c = accum[k] / spp;
         c = fmin(fmax(c, 0.0), 1.0);
         rgb[k] = (uint8_t)(int)(255.0 * c);
@@ -730,7 +730,7 @@ void launch_megakernel(const LaunchCfg& L, const DScene& sc, const DParams& P, d
     if (work) hipLaunchKernelGGL(k_megakernel<true>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, accum, work);
     else hipLaunchKernelGGL(k_megakernel<false>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, accum, work);
 }
-void launch_tonemap(const LaunchCfg& L, const double* accum, int n_values, int spp, uint8_t* rgb) {
+void launch_tonemap(const LaunchCfg& L, const double* accum, long long n_values, int spp, uint8_t* rgb) {
     int g = grid_for(n_values, L.max_blocks);
     hipLaunchKernelGGL(k_tonemap, dim3(g), dim3(CPT_BLOCK), 0, L.stream, accum, n_values, spp, rgb);
 }

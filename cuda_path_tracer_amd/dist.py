@@ -22,10 +22,33 @@ def sample_range(rank, world, first, count):
 def tile_range(rank, world, width, height):
     """Share of the image's 8x8-pixel tiles for `rank` of `world`, as (tile_begin, tile_count) for
     Renderer.params: the way to split one render by area instead of by samples (fewer samples than GPUs, or a
-    single sample to be finished sooner).  Tiles are numbered row by row; ranks get contiguous runs."""
+    single sample to be finished sooner).  Tiles are numbered row by row; ranks get contiguous runs.
+    A rank beyond the number of tiles has nothing to render and gets None (a tile_count of 0 would mean the
+    whole image to cpt_render)."""
     n_tiles = ((width + 7) // 8) * ((height + 7) // 8)
     begin, end = sample_range(rank, world, 0, n_tiles)
+    if end == begin:
+        return None
     return begin, end - begin
+
+
+def shard(rank, world, spp, width, height, scaling="strong"):
+    """What `rank` of `world` renders of an image of `spp` samples per pixel, as a dict of Renderer.params
+    keywords (sample_begin, sample_end, tile_begin, tile_count), or None when the rank has no share.
+    "weak": every rank adds `spp` new sample indices (the image then holds world * spp samples).
+    "strong": the spp samples are dealt out by sample_range; when there are fewer samples than ranks the image is
+    split by area instead and every rank renders all samples of its tiles."""
+    if scaling == "weak":
+        return dict(sample_begin=rank * spp, sample_end=(rank + 1) * spp, tile_begin=0, tile_count=0)
+    if scaling != "strong":
+        raise ValueError("scaling must be 'weak' or 'strong'")
+    if spp >= world:
+        b, e = sample_range(rank, world, 0, spp)
+        return dict(sample_begin=b, sample_end=e, tile_begin=0, tile_count=0)
+    tiles = tile_range(rank, world, width, height)
+    if tiles is None:
+        return None
+    return dict(sample_begin=0, sample_end=spp, tile_begin=tiles[0], tile_count=tiles[1])
 
 
 def reduce_radiance(accum, dst=0, group=None):
@@ -37,7 +60,8 @@ def reduce_radiance(accum, dst=0, group=None):
             # gloo reduces host tensors only: stage through the host (rehearsals on boxes without RCCL peers)
             host = accum.cpu()
             dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
-            accum.copy_(host)
+            if dist.get_rank(group) == dst:  # gloo leaves the other ranks' buffers unspecified: theirs stay as they were
+                accum.copy_(host)
         else:
             dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return accum

@@ -52,7 +52,7 @@ void usage(const char* prog, const Cli& c) {
               << "  --rr        Russian roulette\n"
               << "  --seed <#>  random seed (default 1984)\n"
               << "  --device <#> GPU ordinal (default 0)\n"
-              << "  --batch <#>  path slots per batch (208 bytes each, two batches in flight; default 2^27 at most)\n"
+              << "  --batch <#>  path slots per batch (208 bytes each, two batches in flight; default 2^25, at most 2^28)\n"
               << "  --devices <#,#,...>  split the samples over these GPUs (one host thread and context each)\n"
               << "  --device-bvh        build the BVH on the GPU (a Morton-order tree, not the reference's)\n"
               << "  --progressive <#>   rewrite the output image every # samples per pixel\n"
@@ -60,8 +60,8 @@ void usage(const char* prog, const Cli& c) {
               << "  --metrics <FILE>    write timing and work counters as JSON\n";
 }
 
-// Flat JSON object with numeric values: the keys the reference reads that matter here are
-// "size" and "recursion_depth" (reference: src/ui/TraceUI.cc:46-76).
+// Flat JSON object with numeric values: of the keys the reference reads (src/ui/TraceUI.cc:46-76) "size" and
+// "recursion_depth" are the two this renderer has a setting for.
 bool json_number(const std::string& text, const char* key, double& out) {
     std::string pat = std::string("\"") + key + "\"";
     size_t p = text.find(pat);
@@ -138,6 +138,14 @@ int main(int argc, char** argv) {
         double v;
         if (json_number(ss.str(), "size", v)) c.size = (int)v;
         if (json_number(ss.str(), "recursion_depth", v)) c.depth = (int)v;
+        // The other keys the reference reads (src/ui/TraceUI.cc:52-75) steer its CPU thread pool, its Whitted tracer
+        // and its kd-tree; the GPU path tracer has nothing for them to set, so they are accepted and named.
+        static const char* const unused[] = {"threads", "threshold", "blocksize", "supersamples", "aa_threshold", "tree_depth",
+                                             "leaf_size", "filter_width", "anti_alias", "kdtree", "shadows", "smoothshade",
+                                             "backface_culling", "internal_reflection", "backface_specular"};
+        for (const char* key : unused)
+            if (ss.str().find(std::string("\"") + key + "\"") != std::string::npos)
+                std::cerr << "note: -j key '" << key << "' has no effect on the GPU path tracer" << std::endl;
     }
     if (optind >= argc - 1) {
         std::cerr << "no input and/or output name." << std::endl;

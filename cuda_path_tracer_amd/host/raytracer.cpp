@@ -58,6 +58,21 @@ void RayTracer::traceImage(int w, int h) {
     else traceImageGPU(w, h);
 }
 
+// FNV-1a over the values a render depends on: triangles (vertices, normal, material, flags), vertex normals,
+// materials, camera.  Field by field, so that padding never takes part.
+static uint64_t scene_digest(const FlatScene& s) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](const void* p, size_t n) {
+        const unsigned char* b = (const unsigned char*)p;
+        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    for (const cpt_tri& t : s.tris) { mix(t.a, sizeof t.a); mix(t.b, sizeof t.b); mix(t.c, sizeof t.c); mix(t.n, sizeof t.n); mix(&t.material, 4); mix(&t.flags, 4); }
+    for (const cpt_tri_normals& n : s.tri_normals) { mix(n.na, sizeof n.na); mix(n.nb, sizeof n.nb); mix(n.nc, sizeof n.nc); }
+    for (const cpt_material& m : s.materials) { mix(m.ke, sizeof m.ke); mix(m.kd, sizeof m.kd); mix(m.ks, sizeof m.ks); mix(m.kr, sizeof m.kr); mix(m.kt, sizeof m.kt); mix(&m.index, 8); mix(&m.flags, 4); }
+    mix(s.camera.eye, sizeof s.camera.eye); mix(s.camera.look, sizeof s.camera.look); mix(s.camera.u, sizeof s.camera.u); mix(s.camera.v, sizeof s.camera.v);
+    return h;
+}
+
 void RayTracer::traceImageGPU(int w, int h) { renderGPU(w, h, CPT_MODE_MEGAKERNEL); }
 void RayTracer::betterPathTracing(int w, int h) { renderGPU(w, h, CPT_MODE_WAVEFRONT); }
 
@@ -100,9 +115,15 @@ void RayTracer::renderGPU(int w, int h, int mode) {
     // Long render: chunks, optional checkpoint.  The checkpoint holds the fp64 radiance sums of samples
     // [0, have) and the parameters they depend on; a sample's paths depend only on (pixel, sample
     // index, seed), so resuming adds exactly the samples a single run would have added.
-    struct Header { char magic[8]; int32_t w, h, depth, mode, dof, rr, samples, pad; uint64_t seed; double focal, aperture; };
+    // ... and a digest of the scene and the kind of tree it is rendered on: sums of another scene, or of the same
+    // scene on the other tree (whose ties between equal hits fall differently), must not be continued.
+    struct Header { char magic[8]; int32_t w, h, depth, mode, dof, rr, samples, n_tris; uint64_t seed; double focal, aperture;
+                    uint64_t scene_digest; int32_t device_tree, pad; };
     Header want{};
-    memcpy(want.magic, "CPTCKPT1", 8);
+    memcpy(want.magic, "CPTCKPT2", 8);
+    want.n_tris = (int32_t)scene_->tris.size();
+    want.scene_digest = scene_digest(*scene_);
+    want.device_tree = (scene_->nodes.empty() && scene_->tris.size() > 1) ? 1 : 0;
     want.w = w; want.h = h; want.depth = depth_; want.mode = mode; want.dof = p.dof; want.rr = p.russian_roulette;
     want.seed = p.seed; want.focal = p.focal_distance; want.aperture = p.aperture;
     std::vector<double> accum((size_t)w * h * 3, 0.0);

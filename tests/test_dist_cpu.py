@@ -60,11 +60,29 @@ def test_two_rank_reduce_equals_single_render(tmp_path, oracle_scenes):
 
 def test_tile_range_partitions_the_tiles():
     from cuda_path_tracer_amd.dist import tile_range
-    for (w, h, world) in [(512, 512, 8), (37, 23, 4), (8, 8, 3), (1000, 3, 7)]:
+    for (w, h, world) in [(512, 512, 8), (37, 23, 4), (8, 8, 3), (1000, 3, 7), (16, 8, 5)]:
         n_tiles = ((w + 7) // 8) * ((h + 7) // 8)
         covered = []
         for r in range(world):
-            b, c = tile_range(r, world, w, h)
-            assert 0 <= b and c >= 0 and b + c <= n_tiles
+            share = tile_range(r, world, w, h)
+            if share is None:  # more ranks than tiles: the rank renders nothing (a count of 0 would mean "whole image")
+                assert r >= n_tiles
+                continue
+            b, c = share
+            assert 0 <= b and c >= 1 and b + c <= n_tiles
             covered.extend(range(b, b + c))
         assert covered == list(range(n_tiles))  # contiguous, disjoint, complete, in rank order
+
+
+def test_shard_weak_and_strong():
+    from cuda_path_tracer_amd.dist import shard
+    # weak: every rank adds spp new indices
+    assert [shard(r, 4, 16, 64, 64, "weak")["sample_begin"] for r in range(4)] == [0, 16, 32, 48]
+    # strong, enough samples: the samples are dealt out, whole image each
+    parts = [shard(r, 3, 16, 64, 64) for r in range(3)]
+    assert [(p["sample_begin"], p["sample_end"]) for p in parts] == [(0, 6), (6, 11), (11, 16)]
+    assert all(p["tile_count"] == 0 for p in parts)
+    # strong, fewer samples than ranks: by area, every rank all samples; ranks beyond the tiles get nothing
+    parts = [shard(r, 4, 2, 16, 8) for r in range(4)]
+    assert parts[2] is None and parts[3] is None
+    assert [(p["tile_begin"], p["tile_count"], p["sample_begin"], p["sample_end"]) for p in parts[:2]] == [(0, 1, 0, 2), (1, 1, 0, 2)]

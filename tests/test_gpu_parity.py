@@ -541,6 +541,22 @@ def test_cli_progressive_checkpoint_and_metrics(tmp_path):
     # a checkpoint of another render (different depth) is ignored, not mixed in
     r = subprocess.run([exe, "-g", "-r", "2", "-w", "72", "-s", "3", "--checkpoint", ck, scene, two], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "ignoring" in r.stdout
+    # ... and so is a checkpoint of another scene of the same size and depth, or of the same scene on the other kind of tree
+    ck2 = str(tmp_path / "ck2.bin")
+    r = subprocess.run(base + ["-s", "4", "--checkpoint", ck2, scene, two], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    other = scene_path("cornell-box2-transmissive")
+    three = str(tmp_path / "three.png")
+    r = subprocess.run(base + ["-s", "4", other, three], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    four = str(tmp_path / "four.png")
+    r = subprocess.run(base + ["-s", "4", "--checkpoint", ck2, other, four], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ignoring" in r.stdout
+    assert open(three, "rb").read() == open(four, "rb").read()  # nothing of the first scene was mixed in
+    r = subprocess.run(base + ["-s", "4", "--checkpoint", ck2, other, four], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "resuming" in r.stdout  # the file was replaced by this scene's sums
+    r = subprocess.run(base + ["-s", "4", "--device-bvh", "--checkpoint", ck2, other, four], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ignoring" in r.stdout
 
 
 def test_bench_two_ranks_on_one_gpu():
