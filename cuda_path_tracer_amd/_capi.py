@@ -71,13 +71,14 @@ assert C.sizeof(Node) == 128 and C.sizeof(Tri) == 128 and C.sizeof(TriNormals) =
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)
 
+NOALLOC_SCRATCH_BYTES = 128 << 20  # CPT_NOALLOC_SCRATCH_BYTES
 MODE_WAVEFRONT = 0
 MODE_MEGAKERNEL = 1
 
 # every symbol include/cpt_amd.h declares
 AMD_SYMBOLS = [
     "cpt_create", "cpt_destroy", "cpt_last_error", "cpt_set_stream", "cpt_set_option", "cpt_set_instrumentation",
-    "cpt_upload_scene", "cpt_build_scene", "cpt_refit_scene", "cpt_download_tree", "cpt_render", "cpt_tonemap", "cpt_render_image", "cpt_render_progressive", "cpt_synchronize", "cpt_get_stats",
+    "cpt_upload_scene", "cpt_build_scene", "cpt_refit_scene", "cpt_download_tree", "cpt_render", "cpt_render_noalloc", "cpt_tonemap", "cpt_render_image", "cpt_render_progressive", "cpt_synchronize", "cpt_get_stats",
     "cpt_reset_stats", "cpt_extend_rays", "cpt_trace_rays", "cpt_camera_rays", "cpt_path_radiance", "cpt_probe_math", "cpt_probe_rng",
 ]
 # every symbol include/cpt_host.h declares
@@ -109,6 +110,7 @@ def amd():
         L.cpt_refit_scene.argtypes = [vp, C.POINTER(SceneDesc)]
         L.cpt_download_tree.argtypes = [vp, vp, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]
         L.cpt_render.argtypes = [vp, C.POINTER(RenderParams), vp]
+        L.cpt_render_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp]
         L.cpt_tonemap.argtypes = [vp, vp, i32, i32, i32, vp]
         L.cpt_render_image.argtypes = [vp, C.POINTER(RenderParams), vp]
         L.cpt_render_progressive.argtypes = [vp, C.POINTER(RenderParams), i32, vp, i32, vp, PROGRESS_FN, vp, C.POINTER(i32)]

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <cmath>
 #include <vector>
@@ -22,6 +23,32 @@ static_assert(sizeof(cpt_node) == 128, "cpt_node must be 128 bytes");
 static_assert(sizeof(cpt_tri) == 128, "cpt_tri must be 128 bytes");
 static_assert(sizeof(cpt_tri_normals) == 72, "cpt_tri_normals must be 72 bytes");
 static_assert(sizeof(cpt_material) == 136, "cpt_material must be 136 bytes");
+
+// Working memory of cpt_render_noalloc: ray streams, hit records, per-path radiance, segment counters, claim
+// cursors and stack-spill columns of one batch, carved out of this array instead of out of hipMalloc'ed blocks.
+// Every GPU the library runs on holds its own copy, at its own address, from the moment the code object is
+// loaded until the process ends.  The name is a host-side handle only: the address kernels and memsets use is
+// the one hipGetSymbolAddress returns with that GPU current (static_scratch_for, called by cpt_create).
+static __device__ __align__(256) unsigned char scratch[CPT_NOALLOC_SCRATCH_BYTES];
+#define CPT_MAX_DEVICES 64
+static std::mutex g_scratch_mutex;
+static unsigned char* g_scratch_ptr[CPT_MAX_DEVICES];  // per device: where that GPU keeps `scratch`
+
+// Address of `scratch` on `device`, which must be the current device.  Looked up once per device.
+static hipError_t static_scratch_for(int device, unsigned char** out) {
+    *out = nullptr;
+    if (device < 0 || device >= CPT_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 struct cpt_ctx {
     int device = 0;
@@ -53,6 +80,7 @@ struct cpt_ctx {
     int n_lanes = 2;
     hipEvent_t ev_fork = nullptr;
     unsigned long long* d_work = nullptr;  // paths, segments, hits, node steps, triangle tests
+    unsigned char* d_static_scratch = nullptr;  // this GPU's copy of the file-scope `scratch` array (never freed)
 
     bool time_kernels = false, count_work = false;
     cpt_stats stats{};
@@ -128,9 +156,10 @@ int cpt_create(int device, cpt_ctx** out) {
         if (e == hipSuccess && k > 0) e = hipStreamCreateWithFlags(&c->lanes[k].own_stream, hipStreamNonBlocking);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = static_scratch_for(device, &c->d_static_scratch);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_work, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->d_work, 0, 8 * sizeof(unsigned long long));
-    if (e != hipSuccess) { cpt_destroy(c); return fail(nullptr, CPT_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { cpt_destroy(c); return fail(nullptr, CPT_EHIP, "context set-up: %s", hipGetErrorString(e)); }
     *out = c;
     return CPT_OK;
 }
@@ -491,13 +520,10 @@ int cpt_download_tree(cpt_ctx* c, cpt_node* h_nodes, int32_t node_capacity, uint
     return CPT_OK;
 }
 
-static int ensure_paths(cpt_ctx* c, cpt_ctx::Lane& l, hipStream_t st, size_t slots) {
-    if (slots <= l.path_capacity) return CPT_OK;
-    HIP_TRY(c, hipStreamSynchronize(st));
-    free_paths(l);
-    slots = (slots + 63) / 64 * 64;  // keeps every array 512-byte aligned
-    HIP_TRY(c, hipMalloc(&l.d_paths, slots * CPT_SLOT_BYTES));
-    double* p = (double*)l.d_paths;
+// Lay the arrays of one batch (two ray streams, hit records, per-slot radiance) out in `base`, which holds
+// slots * CPT_SLOT_BYTES bytes and is 256-byte aligned; slots is a multiple of 64, so every array stays 256-byte aligned.
+static void carve_paths(cpt_ctx::Lane& l, void* base, size_t slots) {
+    double* p = (double*)base;
     for (int b = 0; b < 2; ++b) {
         cpt_v2d** f[CPT_STREAM_DOUBLES / 2] = {&l.R[b].oxy, &l.R[b].ozdx, &l.R[b].dyz, &l.R[b].mdax, &l.R[b].ayz};
         for (int k = 0; k < CPT_STREAM_DOUBLES / 2; ++k) { *f[k] = (cpt_v2d*)p; p += 2 * slots; }
@@ -510,6 +536,15 @@ static int ensure_paths(cpt_ctx* c, cpt_ctx::Lane& l, hipStream_t st, size_t slo
     l.R[0].slot = u; u += slots;
     l.R[1].slot = u; u += slots;
     l.path_capacity = slots;
+}
+
+static int ensure_paths(cpt_ctx* c, cpt_ctx::Lane& l, hipStream_t st, size_t slots) {
+    if (slots <= l.path_capacity) return CPT_OK;
+    HIP_TRY(c, hipStreamSynchronize(st));
+    free_paths(l);
+    slots = (slots + 63) / 64 * 64;
+    HIP_TRY(c, hipMalloc(&l.d_paths, slots * CPT_SLOT_BYTES));
+    carve_paths(l, l.d_paths, slots);
     return CPT_OK;
 }
 
@@ -590,6 +625,79 @@ static int collect_work(cpt_ctx* c) {
     return CPT_OK;
 }
 
+// The wavefront pipeline over samples [P.s0, P.s1) in batches of `batch` whole samples, dealt in turn to the
+// n_lanes prepared lanes (lane k on stream st[k]; st[0] is the caller's stream).  Allocates nothing unless
+// `timed` needs more events than the context holds.
+static int run_wavefront(cpt_ctx* c, const DParams& P, LaunchCfg L, cpt_ctx::Lane* const* lanes, const hipStream_t* st, int n_lanes,
+                         int batch, bool timed, unsigned long long* work, double* d_accum) {
+    const long long per_sample = P.n_pix_slots;
+    int rc;
+    const size_t n_ev = 2 * (size_t)(P.depth + 1) + 3;
+    if (timed) { rc = need_events(c, n_ev); if (rc) return rc; }
+    if (n_lanes > 1) {  // the other lanes start after whatever the caller queued before this render
+        HIP_TRY(c, hipEventRecord(c->ev_fork, st[0]));
+        for (int k = 1; k < n_lanes; ++k) HIP_TRY(c, hipStreamWaitEvent(st[k], c->ev_fork, 0));
+    }
+    int last_lane = 0;
+    for (int i = 0, bs = P.s0; bs < P.s1; bs += batch, ++i) {
+        const int k = i % n_lanes;
+        cpt_ctx::Lane& ln = *lanes[k];
+        L.stream = st[k];
+        int bn = std::min(batch, P.s1 - bs);
+        long long slots = (long long)bn * per_sample;
+        size_t ev = 0;
+        uint32_t* cursors = ln.d_cursors;
+        const uint32_t cap = cpt_segment_cap((size_t)slots);
+        HIP_TRY(c, hipMemsetAsync(ln.d_counters, 0, (size_t)(P.depth + 2) * CPT_PW_CURSOR_WORDS * sizeof(uint32_t), L.stream));
+        if (c->extend_variant >= 1) HIP_TRY(c, hipMemsetAsync(cursors, 0, (size_t)(P.depth + 1) * CPT_PW_CURSOR_WORDS * sizeof(uint32_t), L.stream));
+        if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
+        launch_dense_counts(L, ln.d_counters, (uint32_t)slots, cap);  // the first rays sit at positions 0 .. slots-1
+        launch_generate(L, c->sc, P, ln.R[0], ln.C, bs, bn);
+        if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
+        for (int b = 0; b <= P.depth; ++b) {
+            const RayStream& in = ln.R[b & 1];
+            uint32_t* count_in = ln.d_counters + (size_t)b * CPT_PW_CURSOR_WORDS;
+            if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, count_in, cap, cursors + (size_t)b * CPT_PW_CURSOR_WORDS, ln.d_spill, work);
+            else launch_extend(L, c->sc, in, ln.H, count_in, cap, slots, work);
+            if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
+            launch_shade(L, c->sc, P, in, ln.H, ln.R[(b + 1) & 1], ln.C, bs, b, count_in, count_in + CPT_PW_CURSOR_WORDS, cap, slots, work);
+            if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
+        }
+        // a pixel's samples are added in sample order: this batch's resolve follows the previous batch's
+        if (i > 0 && n_lanes > 1) HIP_TRY(c, hipStreamWaitEvent(L.stream, lanes[last_lane]->resolved, 0));
+        launch_resolve(L, P, ln.C, bn, d_accum);
+        HIP_TRY(c, hipGetLastError());
+        if (n_lanes > 1) HIP_TRY(c, hipEventRecord(ln.resolved, L.stream));
+        last_lane = k;
+        c->stats.launches_generate++;
+        c->stats.launches_extend += (uint64_t)(P.depth + 1);
+        c->stats.launches_shade += (uint64_t)(P.depth + 1);
+        c->stats.iterations += (uint64_t)(P.depth + 1);
+        if (timed) {
+            HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
+            HIP_TRY(c, hipEventSynchronize(c->events[ev - 1]));
+            float ms = 0;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->events[0], c->events[1]));
+            c->stats.ms_generate += ms;
+            for (int b = 0; b <= P.depth; ++b) {
+                HIP_TRY(c, hipEventElapsedTime(&ms, c->events[1 + 2 * b], c->events[2 + 2 * b]));
+                c->stats.ms_extend += ms;
+                HIP_TRY(c, hipEventElapsedTime(&ms, c->events[2 + 2 * b], c->events[3 + 2 * b]));
+                c->stats.ms_shade += ms;
+            }
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->events[0], c->events[ev - 1]));
+            c->stats.ms_total += ms;
+        }
+    }
+    // the resolves are chained, so the last one completes the render; the caller's stream waits for it
+    if (n_lanes > 1 && last_lane != 0) HIP_TRY(c, hipStreamWaitEvent(st[0], lanes[last_lane]->resolved, 0));
+    return CPT_OK;
+}
+
+static LaunchCfg launch_cfg(const cpt_ctx* c) {
+    return LaunchCfg{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+}
+
 int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
     if (!c || !p || !d_accum) return c ? fail(c, CPT_EINVAL, "cpt_render: NULL argument") : CPT_EINVAL;
     if (!c->has_scene) return fail(c, CPT_ENOSCENE, "cpt_render: no scene uploaded");
@@ -598,7 +706,7 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
     if (rc != CPT_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     if (P.s1 == P.s0) return CPT_OK;
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L = launch_cfg(c);
     unsigned long long* work = c->count_work ? c->d_work : nullptr;
     const bool timed = c->time_kernels;
     long long n_paths = window_pixels(P) * (P.s1 - P.s0);
@@ -632,82 +740,82 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
     }
     const int n_batches = (total + batch - 1) / batch;
     n_lanes = std::min(n_lanes, n_batches);
+    cpt_ctx::Lane* lanes[CPT_MAX_LANES];
+    hipStream_t st[CPT_MAX_LANES];
     for (int k = 0; k < n_lanes; ++k) {
-        rc = ensure_spill(c, c->lanes[k], lane_stream(c, k));
+        lanes[k] = &c->lanes[k];
+        st[k] = lane_stream(c, k);
+        rc = ensure_spill(c, c->lanes[k], st[k]);
         if (rc) return rc;
-        rc = ensure_paths(c, c->lanes[k], lane_stream(c, k), cpt_stream_positions((size_t)batch * (size_t)per_sample));
+        rc = ensure_paths(c, c->lanes[k], st[k], cpt_stream_positions((size_t)batch * (size_t)per_sample));
         if (rc) return rc;
     }
-    const size_t n_ev = 2 * (size_t)(P.depth + 1) + 3;
-    if (timed) { rc = need_events(c, n_ev); if (rc) return rc; }
-    if (n_lanes > 1) {  // the other lanes start after whatever the caller queued before this render
-        HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-        for (int k = 1; k < n_lanes; ++k) HIP_TRY(c, hipStreamWaitEvent(c->lanes[k].own_stream, c->ev_fork, 0));
-    }
-    int last_lane = 0;
-    for (int i = 0, bs = P.s0; bs < P.s1; bs += batch, ++i) {
-        const int k = i % n_lanes;
-        cpt_ctx::Lane& ln = c->lanes[k];
-        L.stream = lane_stream(c, k);
-        int bn = std::min(batch, P.s1 - bs);
-        long long slots = (long long)bn * per_sample;
-        size_t ev = 0;
-        uint32_t* cursors = ln.d_cursors;
-        const uint32_t cap = cpt_segment_cap((size_t)slots);
-        HIP_TRY(c, hipMemsetAsync(ln.d_counters, 0, (size_t)(P.depth + 2) * CPT_PW_CURSOR_WORDS * sizeof(uint32_t), L.stream));
-        if (c->extend_variant >= 1) HIP_TRY(c, hipMemsetAsync(cursors, 0, (size_t)(P.depth + 1) * CPT_PW_CURSOR_WORDS * sizeof(uint32_t), L.stream));
-        if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
-        launch_dense_counts(L, ln.d_counters, (uint32_t)slots, cap);  // the first rays sit at positions 0 .. slots-1
-        launch_generate(L, c->sc, P, ln.R[0], ln.C, bs, bn);
-        if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
-        for (int b = 0; b <= P.depth; ++b) {
-            const RayStream& in = ln.R[b & 1];
-            uint32_t* count_in = ln.d_counters + (size_t)b * CPT_PW_CURSOR_WORDS;
-            if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, count_in, cap, cursors + (size_t)b * CPT_PW_CURSOR_WORDS, ln.d_spill, work);
-            else launch_extend(L, c->sc, in, ln.H, count_in, cap, slots, work);
-            if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
-            launch_shade(L, c->sc, P, in, ln.H, ln.R[(b + 1) & 1], ln.C, bs, b, count_in, count_in + CPT_PW_CURSOR_WORDS, cap, slots, work);
-            if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
-        }
-        // a pixel's samples are added in sample order: this batch's resolve follows the previous batch's
-        if (i > 0 && n_lanes > 1) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->lanes[last_lane].resolved, 0));
-        launch_resolve(L, P, ln.C, bn, d_accum);
-        HIP_TRY(c, hipGetLastError());
-        if (n_lanes > 1) HIP_TRY(c, hipEventRecord(ln.resolved, L.stream));
-        last_lane = k;
-        c->stats.launches_generate++;
-        c->stats.launches_extend += (uint64_t)(P.depth + 1);
-        c->stats.launches_shade += (uint64_t)(P.depth + 1);
-        c->stats.iterations += (uint64_t)(P.depth + 1);
-        if (timed) {
-            HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
-            HIP_TRY(c, hipEventSynchronize(c->events[ev - 1]));
-            float ms = 0;
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->events[0], c->events[1]));
-            c->stats.ms_generate += ms;
-            for (int b = 0; b <= P.depth; ++b) {
-                HIP_TRY(c, hipEventElapsedTime(&ms, c->events[1 + 2 * b], c->events[2 + 2 * b]));
-                c->stats.ms_extend += ms;
-                HIP_TRY(c, hipEventElapsedTime(&ms, c->events[2 + 2 * b], c->events[3 + 2 * b]));
-                c->stats.ms_shade += ms;
-            }
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->events[0], c->events[ev - 1]));
-            c->stats.ms_total += ms;
-        }
-    }
-    // the resolves are chained, so the last one completes the render; the caller's stream waits for it
-    if (n_lanes > 1 && last_lane != 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->lanes[last_lane].resolved, 0));
+    rc = run_wavefront(c, P, L, lanes, st, n_lanes, batch, timed, work, d_accum);
+    if (rc) return rc;
     c->stats.paths += (uint64_t)n_paths;
     if (work) return collect_work(c);
     return CPT_OK;
 }
 
+// Stack-spill columns the persistent extend kernel can touch on this context's scene: one per stack entry beyond
+// the LDS part, for every thread of every persistent workgroup.
+static size_t spill_bytes_needed(const cpt_ctx* c) {
+    if (c->extend_variant < 1) return 0;
+    const int entries = std::max(c->measured_height, c->tree_height) - 2 - CPT_PW_STACK_LDS_HOST;
+    return entries > 0 ? (size_t)entries * (size_t)c->pw_blocks * CPT_PW_THREADS_HOST * sizeof(uint32_t) : 0;
+}
+
+int cpt_render_noalloc(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
+    if (!c || !p || !d_accum) return c ? fail(c, CPT_EINVAL, "cpt_render_noalloc: NULL argument") : CPT_EINVAL;
+    if (!c->has_scene) return fail(c, CPT_ENOSCENE, "cpt_render_noalloc: no scene uploaded");
+    if (p->mode != CPT_MODE_WAVEFRONT) return fail(c, CPT_EINVAL, "cpt_render_noalloc: wavefront mode only");
+    DParams P;
+    int rc = make_params(c, p, P);
+    if (rc != CPT_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (P.s1 == P.s0) return CPT_OK;
+    // carve this GPU's copy of the static array: segment counters | claim cursors | spill columns | one batch of paths
+    const size_t align = 256;
+    auto up = [&](size_t n) { return (n + align - 1) / align * align; };
+    const size_t counter_bytes = up((size_t)(P.depth + 2) * CPT_PW_CURSOR_WORDS * sizeof(uint32_t));
+    const size_t spill_bytes = up(spill_bytes_needed(c));
+    const size_t fixed = 2 * counter_bytes + spill_bytes;
+    const size_t per_sample = cpt_stream_positions((size_t)P.n_pix_slots);  // slots one sample of the window needs
+    if (fixed >= CPT_NOALLOC_SCRATCH_BYTES || (CPT_NOALLOC_SCRATCH_BYTES - fixed) / CPT_SLOT_BYTES < per_sample)
+        return fail(c, CPT_ELIMIT,
+                    "cpt_render_noalloc: one sample of this window needs %zu bytes of working memory (%zu path slots of %d bytes, "
+                    "%zu bytes of counters and stack spill); the static scratch holds %zu: render a smaller tile window or use cpt_render",
+                    fixed + per_sample * CPT_SLOT_BYTES, per_sample, (int)CPT_SLOT_BYTES, fixed, (size_t)CPT_NOALLOC_SCRATCH_BYTES);
+    // whole samples per batch: what fits (a batch of n samples needs cpt_stream_positions(n * n_pix_slots) slots)
+    const int total = P.s1 - P.s0;
+    const size_t room = (CPT_NOALLOC_SCRATCH_BYTES - fixed) / CPT_SLOT_BYTES;
+    int batch = (int)std::min<size_t>((size_t)total, room / (size_t)P.n_pix_slots);
+    while (batch > 1 && cpt_stream_positions((size_t)batch * (size_t)P.n_pix_slots) > room) --batch;
+    if (batch < 1) batch = 1;
+    const size_t slots = cpt_stream_positions((size_t)batch * (size_t)P.n_pix_slots);
+    unsigned char* base = c->d_static_scratch;  // the device address, never the array's name
+    cpt_ctx::Lane ln;
+    ln.d_counters = (uint32_t*)base;
+    ln.d_cursors = (uint32_t*)(base + counter_bytes);
+    ln.d_spill = (uint32_t*)(base + 2 * counter_bytes);
+    carve_paths(ln, base + fixed, slots);
+    cpt_ctx::Lane* lanes[1] = {&ln};
+    hipStream_t st[1] = {c->stream};
+    // no per-launch timing (it would create events) and no work counting (it would synchronise): one lane, stream-ordered
+    rc = run_wavefront(c, P, launch_cfg(c), lanes, st, 1, batch, false, nullptr, d_accum);
+    if (rc) return rc;
+    c->stats.paths += (uint64_t)(window_pixels(P) * (P.s1 - P.s0));
+    return CPT_OK;
+}
+
 int cpt_tonemap(cpt_ctx* c, const double* d_accum, int32_t w, int32_t h, int32_t total_spp, uint8_t* d_rgb) {
     if (!c || !d_accum || !d_rgb) return c ? fail(c, CPT_EINVAL, "cpt_tonemap: NULL argument") : CPT_EINVAL;
-    if (w < 1 || h < 1 || total_spp < 1) return fail(c, CPT_EINVAL, "cpt_tonemap: bad size or sample count");
+    int size_rc = check_image_size(c, w, h);
+    if (size_rc != CPT_OK) return size_rc;
+    if (total_spp < 1) return fail(c, CPT_EINVAL, "cpt_tonemap: bad sample count %d", total_spp);
     HIP_TRY(c, hipSetDevice(c->device));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
-    launch_tonemap(L, d_accum, w * h * 3, total_spp, d_rgb);
+    LaunchCfg L = launch_cfg(c);
+    launch_tonemap(L, d_accum, (long long)w * h * 3, total_spp, d_rgb);
     HIP_TRY(c, hipGetLastError());
     return CPT_OK;
 }
@@ -828,7 +936,7 @@ int cpt_trace_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, 
     if (h_bitmap) { HIP_TRY(c, bm.alloc(N * (size_t)stride)); HIP_TRY(c, hipMemsetAsync(bm.p, 0, N * (size_t)stride, c->stream)); }
     HIP_TRY(c, hipMemcpyAsync(o.p, h_o, N * 24, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d.p, h_d, N * 24, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L = launch_cfg(c);
     launch_trace_rays(L, c->sc, n, (const double*)o.p, (const double*)d.p, (int*)tri.p, (double*)t.p, (double*)nrm.p,
                       (unsigned long long*)vh.p, (int*)cnt.p, h_bitmap ? (uint8_t*)bm.p : nullptr, stride);
     HIP_TRY(c, hipGetLastError());
@@ -864,7 +972,7 @@ int cpt_extend_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d,
     uint32_t* cursors = ln.d_cursors;
     HIP_TRY(c, hipMemsetAsync(cursors, 0, CPT_PW_CURSOR_WORDS * sizeof(uint32_t), c->stream));
     const uint32_t cap = cpt_segment_cap((size_t)n);
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L = launch_cfg(c);
     unsigned long long* work = c->count_work ? c->d_work : nullptr;
     launch_dense_counts(L, ln.d_counters, (uint32_t)n, cap);
     if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, ln.d_counters, cap, cursors, ln.d_spill, work);
@@ -886,7 +994,7 @@ int cpt_camera_rays(cpt_ctx* c, int32_t w, int32_t h, double jx, double jy, doub
     size_t N = (size_t)w * h;
     DevBuf o, d;
     HIP_TRY(c, o.alloc(N * 24)); HIP_TRY(c, d.alloc(N * 24));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L = launch_cfg(c);
     launch_camera_rays(L, c->sc, w, h, jx, jy, (double*)o.p, (double*)d.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_o, o.p, N * 24, hipMemcpyDeviceToHost, c->stream));
@@ -910,7 +1018,7 @@ int cpt_path_radiance(cpt_ctx* c, const cpt_render_params* p, int32_t n, const i
     size_t N = (size_t)n;
     HIP_TRY(c, ij.alloc(N * 12)); HIP_TRY(c, rad.alloc(N * 24));
     HIP_TRY(c, hipMemcpyAsync(ij.p, h_ijs, N * 12, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L = launch_cfg(c);
     launch_path_radiance(L, c->sc, P, n, (const int*)ij.p, (double*)rad.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_rad, rad.p, N * 24, hipMemcpyDeviceToHost, c->stream));
@@ -927,7 +1035,7 @@ int cpt_probe_math(cpt_ctx* c, int32_t n, const double* h_a, const double* h_b, 
     HIP_TRY(c, a.alloc(N * 8)); HIP_TRY(c, b.alloc(N * 8)); HIP_TRY(c, s.alloc(N * 8)); HIP_TRY(c, q.alloc(N * 8));
     HIP_TRY(c, hipMemcpyAsync(a.p, h_a, N * 8, hipMemcpyHostToDevice, c->stream));
     if (h_b) HIP_TRY(c, hipMemcpyAsync(b.p, h_b, N * 8, hipMemcpyHostToDevice, c->stream));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L = launch_cfg(c);
     launch_probe_math(L, n, (const double*)a.p, h_b ? (const double*)b.p : nullptr, (double*)s.p, (double*)q.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(h_sqrt, s.p, N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -941,7 +1049,7 @@ int cpt_probe_rng(cpt_ctx* c, const uint32_t ctr[4], const uint32_t key[2], uint
     HIP_TRY(c, hipSetDevice(c->device));
     DevBuf o, u;
     HIP_TRY(c, o.alloc(16)); HIP_TRY(c, u.alloc(16));
-    LaunchCfg L{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    LaunchCfg L = launch_cfg(c);
     launch_probe_rng(L, ctr, key, (uint32_t*)o.p, (double*)u.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, o.p, 16, hipMemcpyDeviceToHost, c->stream));

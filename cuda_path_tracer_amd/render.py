@@ -104,6 +104,10 @@ class Renderer:
         """Add samples [begin, end) to a device accumulation buffer (w*h*3 float64) given by address."""
         self._check(self._L.cpt_render(self._h, C.byref(params), C.c_void_p(accum_ptr)), "cpt_render")
 
+    def render_into_noalloc(self, accum_ptr, params):
+        """cpt_render_noalloc: as render_into, with all working memory taken from the library's static device array."""
+        self._check(self._L.cpt_render_noalloc(self._h, C.byref(params), C.c_void_p(accum_ptr)), "cpt_render_noalloc")
+
     def tonemap_into(self, accum_ptr, width, height, total_spp, rgb_ptr):
         self._check(self._L.cpt_tonemap(self._h, C.c_void_p(accum_ptr), width, height, total_spp, C.c_void_p(rgb_ptr)),
                     "cpt_tonemap")

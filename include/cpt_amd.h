@@ -200,6 +200,23 @@ int cpt_download_tree(cpt_ctx* ctx, cpt_node* h_nodes, int32_t node_capacity, ui
  * (reference: src/path_tracer.cu:543-547, src/improved_path_tracer.cu:296-333). */
 int cpt_render(cpt_ctx* ctx, const cpt_render_params* params, double* d_accum);
 
+/* cpt_render for callers that cannot allocate device memory (code under HIP graph capture, serving loops with a
+ * fixed memory budget, harnesses that forbid hipMalloc): the same pipeline, the same kernels and bit for bit the
+ * same sums as cpt_render (wavefront mode only), but all working memory -- ray streams, hit records, per-path
+ * radiance, queue counters, stack-spill columns -- comes from one CPT_NOALLOC_SCRATCH_BYTES array that lives in the
+ * library's device code, so the call makes no hipMalloc / hipFree and creates no events or streams.  It has no
+ * counterpart in the reference (whose render path allocates per object, src/gpu/GPUManaged.cuh:19-24).
+ * Limits: one sample of the tile window must fit, i.e.
+ *   2 * 2 KB * (depth + 2)  +  4 KB * CUs * max(0, tree height - 14)  +  208 B * (pixels of the window, in whole 8x8 tiles)
+ * must not exceed CPT_NOALLOC_SCRATCH_BYTES (a 512x512 image at any accepted tree height does; a 1024x1024 image is
+ * rendered as four tile windows); otherwise CPT_ELIMIT.  Samples are rendered in as large batches as fit, one batch
+ * at a time on the context's stream; instrumentation settings are ignored.  Every context on a GPU shares that
+ * GPU's array: two cpt_render_noalloc calls that overlap in time on one GPU (two contexts, or two streams) race;
+ * calls on one stream, or ordered by events, are safe, and the array needs no clearing between calls (every call
+ * zeroes the counters it uses).  Asynchronous on the context's stream. */
+#define CPT_NOALLOC_SCRATCH_BYTES (128ull << 20)
+int cpt_render_noalloc(cpt_ctx* ctx, const cpt_render_params* params, double* d_accum);
+
 /* mean over total_spp, clamp to [0,1], (int)(255*c) -> d_rgb (device, width*height*3 bytes).
  * Replaces the tail of pathTraceKernel (reference: src/path_tracer.cu:436-443). */
 int cpt_tonemap(cpt_ctx* ctx, const double* d_accum, int32_t width, int32_t height, int32_t total_spp,
