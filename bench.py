@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
 """Benchmark of the path-tracing hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|dragon|cornell2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|dragon|teapot_dof|cornell2]
+                    [--extra dragon,teapot_dof|none] [--scaling weak|strong]
 
 A step renders the whole workload once (all samples of every pixel of every scene in it) with the
-wavefront pipeline, scenes already resident in HBM.  With N > 1 (launched under torch.distributed.run,
-one rank per GPU) every rank renders its own, disjoint range of sample indices of the same image
-(weak scaling: per-GPU work fixed) and the per-rank radiance sums are reduced to rank 0 over RCCL.
-Rank 0 prints one JSON line.
+wavefront pipeline, scenes already resident in HBM.  The headline workload (default: BASELINE configs[1], both
+mixed-lobe Cornell boxes) gives `value`; the other workloads the project is asked to report -- the dragon
+(the BVH-traversal configuration) and the teapot with the thin lens -- are measured in the same run with a few
+steps each and reported under `workloads`, every one with its own roofline record.
+
+With N > 1 there is one rank per GPU (under torch.distributed.run; run as plain `python bench.py --gpus N` the script
+starts that launcher itself, before anything touches a GPU).  Ranks render disjoint shares of the same image and
+the per-rank fp64 radiance sums are reduced to rank 0 over RCCL: `--scaling weak` gives every rank the workload's
+sample count as new sample indices (per-GPU work fixed), `--scaling strong` deals the workload's samples out
+(total work fixed; by image tiles when there are fewer samples than ranks).  Rank 0 prints one JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,6 +28,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
+# fp64 vector issue peak: 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz lane-instructions per second
+# (the 78.6 TFLOP/s vector fp64 peak counts an FMA as two)
+FP64_ISSUE_PEAK = 256 * 4 * 16 * 2.4e9
+# fp64 VALU instructions per lane on the extend kernel's two hot paths, counted in its ISA by
+# tools/count_fp64_isa.py (output committed as profiles/r02_isa_fp64_counts.txt): the division-free test of both
+# child boxes of a node, and one triangle test that runs through all three edge tests.
+F64_PER_NODE_STEP = 70
+F64_PER_TRIANGLE_TEST = 89
 
 WORKLOADS = {
     # the headline configuration: both mixed-lobe Cornell boxes at 512x512, 256 spp, depth 8
@@ -27,10 +44,18 @@ WORKLOADS = {
     # the large-mesh configuration
     "dragon": dict(desc="dragon-spec, 1024x1024, 1024 spp, depth 8", scenes=["dragon-spec"], width=1024, spp=1024,
                    depth=8),
-    # the size the reference's CPU estimator can run
+    # thin lens through the glass teapot; BASELINE quotes 4096 spp spread over 2/4/8 GPUs, here 1024 per GPU
+    "teapot_dof": dict(desc="teapot-trans, thin lens (focal distance 8.1, aperture 0.6), 1024x1024, 1024 spp, depth 8",
+                       scenes=["teapot-trans"], width=1024, spp=1024, depth=8,
+                       render=dict(dof=True, focal_distance=8.1, aperture=0.6)),
+    # the size the reference's CPU estimator is quoted on
     "cornell2": dict(desc="cornell-box2, 512x512, 16 spp, depth 5", scenes=["cornell-box2"], width=512, spp=16,
                      depth=5),
 }
+
+
+if os.environ.get("CPT_BENCH_CORNELL2_SPP"):  # test hook: fewer samples than ranks exercises the tile split
+    WORKLOADS["cornell2"]["spp"] = int(os.environ["CPT_BENCH_CORNELL2_SPP"])
 
 
 def scene_file(name):
@@ -54,11 +79,40 @@ def pipeline_bytes(st):
             + 24 * st["paths"])
 
 
-def cpu_baseline(workload, seconds_target=12.0):
-    """The reference's CPU path tracer (oracle restatement), timed on this box's host cores on a
-    bounded sample of the same workload: a 64x64-pixel render of each scene at the workload's depth."""
+def host_cpus():
+    """(CPUs the machine has, CPUs this process may use): the second honours the affinity mask and a cgroup quota."""
+    total = os.cpu_count() or 1
+    usable = total
+    try:
+        usable = min(usable, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            usable = min(usable, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    forced = os.environ.get("CPT_BENCH_CPU_THREADS")
+    if forced:
+        usable = max(1, int(forced))
+    return total, usable
+
+
+def cpu_baseline(workload, seconds_target=10.0):
+    """The reference's CPU path tracer (oracle restatement: branching estimator, recursive BVH walk, one
+    generator per thread), timed on this box's host cores.  Two measurements: BASELINE configs[0] exactly
+    (cornell-box2, 512x512, 16 spp, depth 5 -- the size the reference's own CPU timings are quoted on), and a bounded
+    sample of the headline workload (64x64 pixels of each scene at its depth, where the branching estimator costs
+    up to 3^depth rays per path)."""
     from oracle import pyoracle
-    threads = min(os.cpu_count() or 1, 16)
+    cores, threads = host_cpus()
+    cfg1 = WORKLOADS["cornell2"]
+    sc = pyoracle.OracleScene(scene_file(cfg1["scenes"][0]))
+    w = cfg1["width"]
+    _, _, s1 = sc.render_cpu_reference(w, w, cfg1["spp"], cfg1["depth"], threads)
+    cfg1_rec = {"workload": cfg1["desc"], "value": w * w * cfg1["spp"] / s1 / 1e6, "unit": "Mpaths/s", "seconds": s1,
+                "paths": w * w * cfg1["spp"], "sample": "the whole configuration, not a sample"}
     paths = 0
     secs = 0.0
     w = 64
@@ -76,137 +130,156 @@ def cpu_baseline(workload, seconds_target=12.0):
                 spp *= 2
         paths += n_scene
         secs += t_scene
-    return {"value": paths / secs / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
-            "sample": "oracle restatement of the reference CPU path tracer (branching estimator, recursive BVH walk), "
-                      "64x64 px of each scene at depth %d, %d paths in %.1f s" % (workload["depth"], paths, secs)}
+    return {"value": paths / secs / 1e6, "unit": "Mpaths/s", "cores": cores, "threads": threads, "kind": "port",
+            "sample": "oracle restatement of the reference CPU path tracer (src/path_tracer.cu:27-238 on the thread pool of "
+                      "src/RayTracer.cpp:657-694), 64x64 px of each scene of the headline workload at depth %d, %d paths in "
+                      "%.1f s on %d threads (machine: %d CPUs)" % (workload["depth"], paths, secs, threads, cores),
+            "cfg1": cfg1_rec}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="wavefront", choices=["wavefront", "mega"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch-paths", type=int, default=1 << 27,
-                    help="path slots per batch; the library's own default (2^25) suits short-lived processes, a long-lived one "
-                         "can afford the larger allocation and gets shorter launch tails (0: library default)")
-    ap.add_argument("--streams", type=int, default=0, help="batches in flight at once (library default when 0)")
-    ap.add_argument("--device-bvh", action="store_true",
-                    help="have the GPU build the BVH (a Morton-order tree) instead of uploading the reference's tree; "
-                         "same image up to ties, different visit sets, so not the parity configuration")
-    ap.add_argument("--opt", action="append", default=[], help="key=value passed to cpt_set_option (tuning experiments)")
-    args = ap.parse_args()
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run with N ranks as a child process --
+    this process has not touched a GPU and never will -- relay its output and exit with its status."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    return subprocess.call(cmd, env=env)
 
-    import torch
-    import torch.distributed as dist
 
-    from cuda_path_tracer_amd import MODE_MEGAKERNEL, MODE_WAVEFRONT, HostScene, Renderer
-    from cuda_path_tracer_amd.dist import reduce_radiance
+class Bench:
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.args = torch, dist, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
+        # CPT_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then share GPUs)
+        self.backend = os.environ.get("CPT_BENCH_BACKEND", "nccl")
+        if self.backend != "nccl":
+            local_rank %= torch.cuda.device_count()
+        self.local_rank = local_rank
+        torch.cuda.set_device(local_rank)
+        self.ranks_seen = 1
+        if self.world > 1:
+            from cuda_path_tracer_amd.dist import reduce_radiance
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(self.backend)
+            # communicator set-up (seconds for RCCL) must never land in a timed region, whatever --warmup says
+            probe = torch.ones(1, dtype=torch.float64, device="cuda")
+            reduce_radiance(probe, dst=0)
+            torch.cuda.synchronize()
+            self.ranks_seen = dist.get_world_size()
+            if self.rank == 0 and int(round(float(probe.item()))) != self.world:
+                raise SystemExit("bench.py: warm-up reduce summed %r, expected %d ranks" % (probe.item(), self.world))
+        self.verbose = bool(os.environ.get("CPT_BENCH_VERBOSE"))
+        # a stream of our own: the legacy default stream serialises against every other stream of the process,
+        # which would keep the renderer's second lane from overlapping the first
+        self.stream = torch.cuda.Stream()
+        torch.cuda.set_stream(self.stream)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
-    # CPT_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then share GPUs)
-    backend = os.environ.get("CPT_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-        # communicator set-up (seconds for RCCL) must never land in the timed region, whatever --warmup says
-        probe = torch.ones(1, dtype=torch.float64, device="cuda")
-        reduce_radiance(probe, dst=0)
-        torch.cuda.synchronize()
+    def say(self, msg):
+        if self.verbose:
+            print("[bench rank %d] %s" % (self.rank, msg), file=sys.stderr, flush=True)
 
-    verbose = bool(os.environ.get("CPT_BENCH_VERBOSE"))
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
 
-    def say(msg):
-        if verbose:
-            print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
+    def measure(self, key, steps, warmup, with_roofline=True):
+        """Time `steps` steps of workload `key` after `warmup` untimed ones; returns the record (rank 0) or None."""
+        torch, dist, args = self.torch, self.dist, self.args
+        from cuda_path_tracer_amd import MODE_MEGAKERNEL, MODE_WAVEFRONT, HostScene, Renderer
+        from cuda_path_tracer_amd.dist import reduce_radiance, shard
+        wl = WORKLOADS[key]
+        world, rank = self.world, self.rank
+        mode = MODE_WAVEFRONT if args.mode == "wavefront" else MODE_MEGAKERNEL
+        renderers = []
+        for name in wl["scenes"]:
+            hs = HostScene(scene_file(name))
+            r = Renderer(self.local_rank)
+            r.set_stream(self.stream.cuda_stream)
+            if args.batch_paths:
+                r.set_option("batch_paths", args.batch_paths)
+            if args.streams:
+                r.set_option("streams", args.streams)
+            for kv in args.opt:
+                k, v = kv.split("=")
+                r.set_option(k, int(v))
+            if args.device_bvh:
+                r.build(hs)
+            else:
+                r.upload(hs)
+            w = wl["width"]
+            h = hs.height_for_width(w)
+            acc = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+            rgb = torch.zeros(h, w, 3, dtype=torch.uint8, device="cuda")
+            renderers.append((r, hs, w, h, acc, rgb))
+        spp = wl["spp"]
+        total_spp = spp * world if args.scaling == "weak" else spp
+        extra = wl.get("render", {})
 
-    say("process group up, backend %s, device %d" % (backend if world > 1 else "-", local_rank))
-    wl = WORKLOADS[args.workload]
-    mode = MODE_WAVEFRONT if args.mode == "wavefront" else MODE_MEGAKERNEL
-    # a stream of our own: the legacy default stream serialises against every other stream of the process,
-    # which would keep the renderer's second lane from overlapping the first
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    renderers = []
-    for name in wl["scenes"]:
-        hs = HostScene(scene_file(name))
-        r = Renderer(local_rank)
-        r.set_stream(stream.cuda_stream)
-        if args.batch_paths:
-            r.set_option("batch_paths", args.batch_paths)
-        if args.streams:
-            r.set_option("streams", args.streams)
-        for kv in args.opt:
-            k, v = kv.split("=")
-            r.set_option(k, int(v))
-        if args.device_bvh:
-            r.build(hs)
-        else:
-            r.upload(hs)
-        w = wl["width"]
-        h = hs.height_for_width(w)
-        acc = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
-        rgb = torch.zeros(h, w, 3, dtype=torch.uint8, device="cuda")
-        renderers.append((r, hs, w, h, acc, rgb))
-    spp = wl["spp"]
-    s0, s1 = rank * spp, (rank + 1) * spp  # weak scaling: every rank adds `spp` new sample indices
+        def step(collective=True):
+            for (r, hs, w, h, acc, rgb) in renderers:
+                acc.zero_()
+                share = shard(rank, world, spp, w, h, args.scaling)
+                if share is not None:
+                    r.render_into(acc.data_ptr(), r.params(w, h, share["sample_begin"], share["sample_end"], wl["depth"], mode=mode,
+                                                           tile_begin=share["tile_begin"], tile_count=share["tile_count"], **extra))
+                if collective:
+                    reduce_radiance(acc, dst=0)
+                if rank == 0:
+                    r.tonemap_into(acc.data_ptr(), w, h, total_spp, rgb.data_ptr())
 
-    def step(collective=True):
-        for (r, hs, w, h, acc, rgb) in renderers:
-            acc.zero_()
-            r.render_into(acc.data_ptr(), r.params(w, h, s0, s1, wl["depth"], mode=mode))
-            if collective:
-                reduce_radiance(acc, dst=0)
-            if rank == 0:
-                r.tonemap_into(acc.data_ptr(), w, h, spp * world, rgb.data_ptr())
-
-    def fence():
-        torch.cuda.synchronize()
+        self.say("%s: scenes uploaded" % key)
+        for _ in range(warmup):
+            step()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        self.say("%s: timed steps done in %.3f s" % (key, elapsed))
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        paths_per_step = sum(w * h * total_spp for (_, _, w, h, _, _) in renderers)  # all ranks together
+        rec = None
+        if rank == 0:
+            rec = {"workload": wl["desc"], "value": steps * paths_per_step / elapsed / 1e6, "unit": "Mpaths/s",
+                   "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "paths_per_step": paths_per_step}
+            if with_roofline:
+                rec["roofline"] = self.roofline(key, renderers, step, mode)
+        for (r, *_rest) in renderers:
+            r.close()
+        del renderers
+        torch.cuda.empty_cache()
+        if world > 1:
+            dist.barrier()  # the other ranks wait here while rank 0 runs its instrumented steps
+        return rec
 
-    say("scenes uploaded")
-    for _ in range(args.warmup):
-        step()
-        say("warmup step queued")
-    fence()
-    say("warmup done")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    say("timed steps done in %.3f s" % elapsed)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    paths_per_step_per_gpu = sum(w * h * spp for (_, _, w, h, _, _) in renderers)
-    value = world * args.steps * paths_per_step_per_gpu / elapsed / 1e6
-
-    out = None
-    if rank == 0:
-        # one instrumented step for per-kernel HIP-event time, one counting step for the work done
-        roof = None
+    def roofline(self, key, renderers, step, mode):
+        """One step with per-launch HIP-event timing (one batch at a time, so a kernel's time is its own) and one with
+        the device-side work counters, on rank 0 alone; from them the extend kernel's rates."""
+        torch = self.torch
+        from cuda_path_tracer_amd import MODE_WAVEFRONT
         for (r, *_rest) in renderers:
             r.reset_stats()
             r.set_instrumentation(time_kernels=True, count_work=False)
-        step(collective=False)  # rank 0 alone: the other ranks are already at the final barrier
+        step(collective=False)
         torch.cuda.synchronize()
         timed = [r.stats() for (r, *_rest) in renderers]
         for (r, *_rest) in renderers:
@@ -219,62 +292,115 @@ def main():
             r.set_instrumentation(False, False)
         agg = {k: sum(c[k] for c in counted) for k in ("paths", "segments", "hits", "node_steps", "tri_tests",
                                                         "exact_node_steps", "box_passes", "leaf_passes")}
-        if mode == MODE_WAVEFRONT:
-            ms = sum(t["ms_extend"] for t in timed)
-            launches = sum(t["launches_extend"] for t in timed)
-            kernel, kbytes = "k_extend_pw", extend_bytes(agg)
-        else:
-            ms = sum(t["ms_mega"] for t in timed)
-            launches = sum(t["launches_mega"] for t in timed)
-            kernel, kbytes = "k_megakernel", pipeline_bytes(agg)
-        achieved = kbytes / (ms * 1e-3) / 1e9
+        kernel_ms = {k: sum(t[k] for t in timed) for k in ("ms_generate", "ms_extend", "ms_shade", "ms_mega", "ms_total")}
+        if mode != MODE_WAVEFRONT:
+            ms, launches = kernel_ms["ms_mega"], sum(t["launches_mega"] for t in timed)
+            gbps = pipeline_bytes(agg) / (ms * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": "k_megakernel", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": gbps / HBM_PEAK_GBPS, "traffic": None, "avg_launch_ms": ms / max(launches, 1),
+                    "note": "one thread per pixel (the reference's kernel shape), kept as an A/B; algorithmic bytes of the whole path",
+                    "kernel_ms_per_step": kernel_ms}
+        ms = kernel_ms["ms_extend"]
+        launches = sum(t["launches_extend"] for t in timed)
+        secs = ms * 1e-3
+        useful = F64_PER_NODE_STEP * agg["node_steps"] + F64_PER_TRIANGLE_TEST * agg["tri_tests"]
+        occupied = 64.0 * (F64_PER_NODE_STEP * agg["box_passes"] + F64_PER_TRIANGLE_TEST * agg["leaf_passes"])
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.workload, {}).get(kernel)
+                traffic = json.load(open(tfile)).get(key, {}).get("k_extend_pw")
             except Exception:
                 traffic = None
-        # fp64 instruction issue, the resource the extend kernel actually runs out of: instructions per lane on its two
-        # hot paths (counted in the kernel's ISA: 75 per node expansion with both box tests, 89 per triangle test)
-        # against 256 CUs x 4 SIMDs x 16 lanes per cycle at 2.4 GHz.  `useful` counts lanes that had work,
-        # `occupied` every lane of the passes that ran.
-        fp64_peak = 256 * 4 * 16 * 2.4e9
-        fp64 = None
-        if mode == MODE_WAVEFRONT and ms > 0:
-            useful = 75.0 * agg["node_steps"] + 89.0 * agg["tri_tests"]
-            occupied = 75.0 * 64 * agg["box_passes"] + 89.0 * 64 * agg["leaf_passes"]
-            fp64 = {"per_node_step": 75, "per_triangle_test": 89, "peak_Tinstr_per_s": fp64_peak / 1e12,
-                    "useful_frac": useful / (ms * 1e-3) / fp64_peak, "occupied_frac": occupied / (ms * 1e-3) / fp64_peak}
-        roof = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "bytes_per_launch": kbytes / max(launches, 1), "avg_launch_ms": ms / max(launches, 1),
-                "launches_per_step": launches,
-                "note": "algorithmic bytes count every node and triangle record a ray touches; the kernel serves them "
-                        "from a per-CU LDS copy (and L2), so the rate can exceed the HBM peak and `traffic` (measured HBM "
-                        "bytes per launch) is far below bytes_per_launch; the kernel's physical bound is fp64 VALU issue",
-                "lane_slots_used": {"box": agg["node_steps"] / max(64 * agg["box_passes"], 1),
-                                    "triangle": agg["tri_tests"] / max(64 * agg["leaf_passes"], 1)},
-                "exact_box_fallbacks": agg["exact_node_steps"], "fp64_issue": fp64,
-                "pipeline_GBps": pipeline_bytes(agg) / (sum(t["ms_total"] for t in timed) * 1e-3) / 1e9,
-                "per_segment": {"node_steps": agg["node_steps"] / max(agg["segments"], 1),
-                                "tri_tests": agg["tri_tests"] / max(agg["segments"], 1),
-                                "segments_per_path": agg["segments"] / max(agg["paths"], 1)},
-                "kernel_ms_per_step": {k: sum(t[k] for t in timed) for k in
-                                       ("ms_generate", "ms_extend", "ms_shade", "ms_mega", "ms_total")}}
-        out = {"metric": "Mpaths/s", "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        kbytes = extend_bytes(agg)
+        avg_ms = ms / max(launches, 1)
+        hbm_measured = None
+        if traffic:
+            hbm_measured = {"bytes_per_launch": traffic, "GBps": traffic / (avg_ms * 1e-3) / 1e9,
+                            "frac_of_hbm_peak": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                            "source": "profiles/traffic.json (rocprofv3 PMC passes, TCC_EA0 read/write requests, one batch at a time)"}
+        return {
+            # the resource the kernel runs out of: fp64 vector instruction issue.  achieved = fp64 lane-instructions of
+            # lanes that had work (node expansions and triangle tests are fixed by the rays, the per-unit instruction
+            # counts by the kernel's ISA) per second of extend-kernel time; peak = every SIMD issuing fp64 every cycle.
+            "bound": "fp64_valu_issue", "kernel": "k_extend_pw", "achieved": useful / secs / 1e12,
+            "peak": FP64_ISSUE_PEAK / 1e12, "unit": "T fp64 lane-instructions/s", "frac": useful / secs / FP64_ISSUE_PEAK,
+            "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": launches,
+            "instr_per_node_step": F64_PER_NODE_STEP, "instr_per_triangle_test": F64_PER_TRIANGLE_TEST,
+            "isa_evidence": "profiles/r02_isa_fp64_counts.txt (tools/count_fp64_isa.py)",
+            "occupied_frac": occupied / secs / FP64_ISSUE_PEAK,
+            "lane_slots_used": {"box": agg["node_steps"] / max(64 * agg["box_passes"], 1),
+                                "triangle": agg["tri_tests"] / max(64 * agg["leaf_passes"], 1)},
+            # secondary yardsticks, neither of them this kernel's bound: the algorithmic-byte rate (every node and
+            # triangle record a ray touches, served from the per-CU LDS copy and L2, so it may exceed the HBM peak) and
+            # the HBM traffic the counters measured
+            "hbm_algorithmic": {"bytes_per_launch": kbytes / max(launches, 1), "GBps": kbytes / secs / 1e9,
+                                "ratio_to_hbm_peak": kbytes / secs / 1e9 / HBM_PEAK_GBPS,
+                                "note": "records are served from LDS/L2, not HBM: a yardstick across implementations, not a bound"},
+            "hbm_measured": hbm_measured,
+            "exact_box_fallbacks": agg["exact_node_steps"],
+            "pipeline_algorithmic_GBps": pipeline_bytes(agg) / (kernel_ms["ms_total"] * 1e-3) / 1e9,
+            "per_segment": {"node_steps": agg["node_steps"] / max(agg["segments"], 1),
+                            "tri_tests": agg["tri_tests"] / max(agg["segments"], 1),
+                            "segments_per_path": agg["segments"] / max(agg["paths"], 1)},
+            "kernel_ms_per_step": kernel_ms}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS), help="the headline workload (`value`)")
+    ap.add_argument("--extra", default="dragon,teapot_dof",
+                    help="comma-separated workloads also measured (2 steps each) and reported under `workloads`; 'none' for none")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank renders the workload's sample count (new sample indices per rank); strong: the "
+                         "workload's samples are dealt out over the ranks")
+    ap.add_argument("--mode", default="wavefront", choices=["wavefront", "mega"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-paths", type=int, default=1 << 27,
+                    help="path slots per batch; the library's own default (2^25) suits short-lived processes, a long-lived one "
+                         "can afford the larger allocation and gets shorter launch tails (0: library default)")
+    ap.add_argument("--streams", type=int, default=0, help="batches in flight at once (library default when 0)")
+    ap.add_argument("--device-bvh", action="store_true",
+                    help="have the GPU build the BVH (a Morton-order tree) instead of uploading the reference's tree; "
+                         "same image up to ties, different visit sets, so not the parity configuration")
+    ap.add_argument("--opt", action="append", default=[], help="key=value passed to cpt_set_option (tuning experiments)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    names = [] if args.extra in ("", "none") else [n for n in args.extra.split(",") if n and n != args.workload]
+    for name in names:
+        if name not in WORKLOADS:
+            raise SystemExit("bench.py: unknown workload '%s' in --extra" % name)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    b = Bench(args)
+    wl = WORKLOADS[args.workload]
+    head = b.measure(args.workload, args.steps, args.warmup)
+    extras = {}
+    for name in names:
+        extras[name] = b.measure(name, 2, 1)
+    if b.rank == 0:
+        world = b.world
+        out = {"metric": "Mpaths/s", "value": head["value"], "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+               "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": wl["desc"], "mode": args.mode, "batch_paths": args.batch_paths,
-                          "bvh": "built on the GPU (Morton order)" if args.device_bvh else "reference tree (host build)", "paths_per_step": world * paths_per_step_per_gpu,
-                          "sharding": "spp range per rank, fp64 radiance reduce to rank 0" if world > 1 else "single GPU"},
-               "roofline": roof}
+                          "bvh": "built on the GPU (Morton order)" if args.device_bvh else "reference tree (host build)",
+                          "paths_per_step": head["paths_per_step"],
+                          "sharding": ("spp range per rank (%s scaling), fp64 radiance reduce to rank 0" % args.scaling)
+                                      if world > 1 else "single GPU",
+                          "rccl_ranks": b.ranks_seen, "backend": b.backend if world > 1 else None},
+               "roofline": head["roofline"], "workloads": extras}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if b.world > 1:
+        b.dist.barrier()
+        b.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -559,31 +559,62 @@ def test_cli_progressive_checkpoint_and_metrics(tmp_path):
     assert r.returncode == 0 and "ignoring" in r.stdout
 
 
-def test_bench_two_ranks_on_one_gpu():
-    """bench.py --gpus 2 under torch.distributed.run, rehearsed on one GPU (both ranks share it; gloo stands
-    in for RCCL, which refuses two ranks on one device): the N > 1 path -- sample sharding, the reduce,
-    the max-over-ranks timing, rank 0's solo instrumentation steps, the final barrier -- runs to the end
-    and prints one JSON line."""
+@pytest.mark.parametrize("scaling,launcher", [("weak", "torchrun"), ("strong", "self"), ("strong-tiles", "self")])
+def test_bench_two_ranks_on_one_gpu(scaling, launcher):
+    """bench.py --gpus 2, rehearsed on one GPU (both ranks share it; gloo stands in for RCCL, which refuses two ranks
+    on one device): the N > 1 path -- sharding, the reduce, the max-over-ranks timing, rank 0's solo instrumentation
+    steps, the final barrier -- runs to the end and prints one JSON line.  Under torch.distributed.run as the driver
+    starts it, and as plain `python bench.py --gpus 2`, which starts the launcher itself; weak scaling (every rank
+    adds the workload's sample count), strong scaling by samples, and strong scaling by tiles (a workload with
+    fewer samples than ranks is not among the named ones, so that case uses the library call directly below)."""
     import json
     import os
     import socket
     import subprocess
     import sys
     from conftest import ROOT
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, CPT_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--workload", "cornell2", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env, cwd=ROOT)
+    env.pop("WORLD_SIZE", None)
+    tail = ["--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "cornell2", "--extra", "none", "--no-cpu-baseline",
+            "--scaling", "weak" if scaling == "weak" else "strong"]
+    if launcher == "torchrun":
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")] + tail
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + tail
+    if scaling == "strong-tiles":
+        env["CPT_BENCH_CORNELL2_SPP"] = "1"  # one sample for two ranks: the image is split by tiles
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=200, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
-    assert out["config"]["paths_per_step"] == 2 * 512 * 512 * 16
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["rccl_ranks"] == 2
+    if scaling == "weak":
+        assert out["scaling"] == "weak" and out["config"]["paths_per_step"] == 2 * 512 * 512 * 16
+    elif scaling == "strong":
+        assert out["scaling"] == "strong" and out["config"]["paths_per_step"] == 512 * 512 * 16
+    else:
+        assert out["scaling"] == "strong" and out["config"]["paths_per_step"] == 512 * 512
+    assert 0 < out["roofline"]["frac"] <= 1 and out["roofline"]["bound"] == "fp64_valu_issue"
+
+
+def test_bench_fails_when_a_rank_fails():
+    """A rank that dies makes the self-launched bench exit non-zero and print no result line (here every rank
+    refuses an option the library does not know)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, CPT_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "cornell2",
+                        "--extra", "none", "--opt", "no_such_option=1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=200, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_deep_stacks_spill_past_the_lds_entries(tmp_path, gpu, oracle):
