@@ -45,6 +45,20 @@ def main():
         print(scene, depth, est, f, "mean", blocks.mean())
     np.savez_compressed(os.path.join(HERE, "reference_blocks.npz"), **arrays)
     json.dump(names, open(os.path.join(HERE, "reference_blocks.json"), "w"), indent=1, sort_keys=True)
+    # The showcase renders (important_assets/Renders/*.bmp|png, 512x512, 16 384 samples per pixel by their names;
+    # README.md:49).  Their file names do not say at which depth they were made: the tests that use them say so.
+    # (dragon-split-spec-16384.bmp and dragon-split-trans-16384.bmp are left out: their mean levels, 32.4 and 45.2,
+    # are far below what the shipped dragon-spec.ray / dragon-trans.ray give at any depth (57.7 at depth 1, rising
+    # with depth), so they were rendered from another revision of those scenes and pin nothing.)
+    show = {"cornell-box": "cornell-box-16384.bmp", "teapot-trans": "teapot-trans-16384-5.png"}
+    arrays = {}
+    for scene, f in sorted(show.items()):
+        img = np.asarray(Image.open(os.path.join(ref, "important_assets", "Renders", f)).convert("RGB"), np.float64)
+        assert img.shape == (512, 512, 3), (f, img.shape)
+        arrays[scene] = img[::-1].reshape(64, 8, 64, 8, 3).mean(axis=(1, 3)).astype(np.float32)
+        print("showcase", scene, f, "mean", arrays[scene].mean())
+    np.savez_compressed(os.path.join(HERE, "showcase_blocks.npz"), **arrays)
+    json.dump(show, open(os.path.join(HERE, "showcase_blocks.json"), "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

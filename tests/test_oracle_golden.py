@@ -131,3 +131,46 @@ def test_depth_of_field_and_roulette_are_unbiased_variants(oracle_scenes):
     assert abs(rr.mean() - base.mean()) / base.mean() < 0.15
     dof, _ = sc.render(16, 16, 0, 8, 2, dof=1, focal=6.0, aperture=0.2)
     assert np.isfinite(dof).all() and dof.sum() > 0
+
+
+@pytest.mark.parametrize("scene,depth", [("cornell-box", 3), ("cornell-box2-specular", 3), ("cornell-box2-transmissive", 3)])
+def test_oracle_estimator_against_reference_renders_blockwise(scene, depth, oracle_scenes):
+    """The oracle itself (not the GPU product) against the reference's own golden renders, one scene per lobe:
+    all-diffuse, with a mirror lobe, with a dielectric lobe.
+
+    tests/golden/reference_blocks.npz holds the mean RGB of every 8x8-pixel block of the reference's 512x512
+    renders.  Rendering whole images at the golden files' sample counts is beyond a CPU test, so the oracle renders
+    64 of the 4096 blocks -- a regular 8x8 lattice over the image -- at the reference's resolution and pixel
+    semantics (jittered samples of the 512x512 pixel, mean, clamp, truncation to 8 bits, then the block mean),
+    1024 samples per pixel in two halves.  The halves give the noise sigma of a block mean; the reference's block
+    must be no further from the oracle's than 1.5 sigma + 0.25 in RMS over the lattice (0-255 scale, the two
+    worst blocks set aside as in the GPU test: a light's outline falls a fraction of a pixel differently in the
+    golden files), for the reference's GPU render and for its CPU render."""
+    ref = np.load(os.path.join(GOLD, "reference_blocks.npz"))
+    sc = oracle_scenes(scene)
+    half = 512
+    lattice = [(8 * gx + 3, 8 * gy + 4) for gy in range(8) for gx in range(8)]
+    px = np.array([(8 * bx + i, 8 * by + j) for (bx, by) in lattice for j in range(8) for i in range(8)], np.int32)
+    sums = []
+    for s0 in (0, half):
+        ijs = np.empty((px.shape[0] * half, 3), np.int32)
+        ijs[:, 0] = np.repeat(px[:, 0], half)
+        ijs[:, 1] = np.repeat(px[:, 1], half)
+        ijs[:, 2] = np.tile(np.arange(s0, s0 + half, dtype=np.int32), px.shape[0])
+        sums.append(sc.paths(512, 512, depth, ijs).reshape(px.shape[0], half, 3).sum(axis=1))
+
+    def block_means(acc, n):  # (64 blocks, 3): the reference's quantiser per pixel (src/path_tracer.cu:436-443), then the mean
+        return np.floor(255.0 * np.clip(acc / n, 0.0, 1.0)).reshape(64, 64, 3).mean(axis=1)
+
+    def rms(a, b, drop=0):
+        sq = ((a - b) ** 2).mean(axis=1)
+        sq.sort()
+        return float(np.sqrt(sq[:sq.size - drop].mean()))
+    both = block_means(sums[0] + sums[1], 2 * half)
+    sigma = rms(block_means(sums[0], half), block_means(sums[1], half)) / 2.0
+    for est in ("gpu", "cpu"):
+        blocks = ref["%s|%d|%s" % (scene, depth, est)].astype(np.float64)
+        want = np.array([blocks[by, bx] for (bx, by) in lattice])
+        got = rms(both, want, drop=2)
+        assert got < 1.5 * sigma + 0.25, (est, got, sigma)
+        assert abs(both.mean() - want.mean()) < 1.5, (est, both.mean(), want.mean())
