@@ -14,6 +14,8 @@ class BuildMissing(RuntimeError):
 
 def _load(name):
     path = os.path.join(_HERE, name)
+    if name == "libcpt_amd.so" and os.environ.get("CPT_AMD_LIBRARY"):  # A/B builds of the GPU library (tuning experiments)
+        path = os.path.abspath(os.environ["CPT_AMD_LIBRARY"])
     if not os.path.exists(path):
         raise BuildMissing(
             "%s is not built. Run `make -C %s` (or `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -209,7 +209,9 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
 // Queue entries are claimed in chunks: one atomic per `chunk` rays, the rest is wave-local.
 // The per-lane node stack keeps its first CPT_PW_STACK_LDS entries in LDS; deeper entries (rare)
 // go to a per-lane column of `spill` in global memory.
+#ifndef CPT_PW_THREADS
 #define CPT_PW_THREADS 1024
+#endif
 #define CPT_PW_WAVES (CPT_PW_THREADS / CPT_WAVE)
 #define CPT_PW_CACHE_RECORDS 512  // 64 KB of 128-byte records
 #define CPT_PW_STACK_LDS 12
@@ -451,8 +453,11 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
 // Register budget: 96 VGPRs (five waves per SIMD) at the price of 28 spilled registers.  Run alone the kernel is 5 %
 // slower than with 128 VGPRs and no spills, but the pipeline keeps two batches in flight, and beside the other
 // batch's extend kernel the smaller footprint wins: +4 % on whole renders (six waves: the same; eight: -17 %).
+#ifndef CPT_SHADE_MIN_WAVES
+#define CPT_SHADE_MIN_WAVES 5
+#endif
 template <bool COUNT, bool FIRST>
-__global__ void __launch_bounds__(CPT_SHADE_BLOCK, 5) k_shade(DScene sc, DParams P, RayStream in, HitBuf hit, RayStream out,
+__global__ void __launch_bounds__(CPT_SHADE_BLOCK, CPT_SHADE_MIN_WAVES) k_shade(DScene sc, DParams P, RayStream in, HitBuf hit, RayStream out,
                                                            Radiance col, int batch_s0, int bounce,
                                                            const uint32_t* __restrict__ counter_in, uint32_t* counter_out, uint32_t cap,
                                                            unsigned long long* work) {
