@@ -197,8 +197,9 @@ class Bench:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
-    def measure(self, key, steps, warmup, with_roofline=True):
-        """Time `steps` steps of workload `key` after `warmup` untimed ones; returns the record (rank 0) or None."""
+    def measure(self, key, steps, warmup, with_roofline=True, options=()):
+        """Time `steps` steps of workload `key` after `warmup` untimed ones; returns the record (rank 0) or None.
+        `options`: (key, value) pairs for cpt_set_option on top of the command line's."""
         torch, dist, args = self.torch, self.dist, self.args
         from cuda_path_tracer_amd import MODE_MEGAKERNEL, MODE_WAVEFRONT, HostScene, Renderer
         from cuda_path_tracer_amd.dist import reduce_radiance, shard
@@ -216,6 +217,8 @@ class Bench:
                 r.set_option("streams", args.streams)
             for kv in args.opt:
                 k, v = kv.split("=")
+                r.set_option(k, int(v))
+            for (k, v) in options:
                 r.set_option(k, int(v))
             if args.device_bvh:
                 r.build(hs)
@@ -359,6 +362,7 @@ def main():
                          "workload's samples are dealt out over the ranks")
     ap.add_argument("--mode", default="wavefront", choices=["wavefront", "mega"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-modes", action="store_true", help="skip the extra measurements of extend variants 3 and 4")
     ap.add_argument("--batch-paths", type=int, default=1 << 27,
                     help="path slots per batch; the library's own default (2^25) suits short-lived processes, a long-lived one "
                          "can afford the larger allocation and gets shorter launch tails (0: library default)")
@@ -383,6 +387,23 @@ def main():
     extras = {}
     for name in names:
         extras[name] = b.measure(name, 2, 1)
+    # The fast modes, beside the numbers above and never instead of them: the same closest hits (so the same image,
+    # bit for bit) from a walk that is not the reference's.  3: inner nodes through a conservative binary32 box test,
+    # every leaf through the exact test of its own box; 4: the same, nearer child first, boxes beyond the closest hit
+    # so far skipped.
+    fast = {}
+    if not args.no_fast_modes and args.mode == "wavefront":
+        for name in [args.workload] + names:
+            rec = {}
+            for label, variant in (("binary32_inner_nodes", 3), ("binary32_inner_nodes_and_culling", 4)):
+                r = b.measure(name, 2, 1, with_roofline=False, options=(("extend_variant", variant),))
+                if r is not None:
+                    rec[label] = {"value": r["value"], "unit": "Mpaths/s", "ms_per_step": r["ms_per_step"]}
+            if b.rank == 0:
+                base = head["value"] if name == args.workload else extras[name]["value"]
+                for label in rec:
+                    rec[label]["speedup_over_reference_walk"] = rec[label]["value"] / base
+                fast[name] = rec
     if b.rank == 0:
         world = b.world
         out = {"metric": "Mpaths/s", "value": head["value"], "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps,
@@ -394,7 +415,7 @@ def main():
                           "sharding": ("spp range per rank (%s scaling), fp64 radiance reduce to rank 0" % args.scaling)
                                       if world > 1 else "single GPU",
                           "rccl_ranks": b.ranks_seen, "backend": b.backend if world > 1 else None},
-               "roofline": head["roofline"], "workloads": extras}
+               "roofline": head["roofline"], "workloads": extras, "fast_modes": fast}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)

@@ -55,7 +55,8 @@ struct cpt_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string err;
 
-    void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr;
+    void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_nodes32 = nullptr;
+    double scene_extent = 0.0;  // largest box-plane magnitude (of the root's two child boxes)
     DScene sc{};
     bool has_scene = false;
     int n_tree_nodes = 0, tree_height = 0, measured_height = 0;
@@ -120,7 +121,8 @@ static void free_scene(cpt_ctx* c) {
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_tris) (void)hipFree(c->d_tris);
     if (c->d_shade) (void)hipFree(c->d_shade);
-    c->d_nodes = c->d_tris = c->d_shade = nullptr;
+    if (c->d_nodes32) (void)hipFree(c->d_nodes32);
+    c->d_nodes = c->d_tris = c->d_shade = c->d_nodes32 = nullptr;
     c->has_scene = false;
 }
 static void free_paths(cpt_ctx::Lane& l) {
@@ -235,7 +237,7 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
         if (value < 1 || value > 64) return fail(c, CPT_EINVAL, "pw_leaf_go must be in [1, 64]");
         c->pw_leaf_go = (int)value;
     } else if (!strcmp(key, "extend_variant")) {
-        if (value < 0 || value > 2) return fail(c, CPT_EINVAL, "extend_variant must be 0, 1 or 2");
+        if (value < 0 || value > 4) return fail(c, CPT_EINVAL, "extend_variant must be 0 .. 4");
         c->extend_variant = (int)value;
     } else {
         return fail(c, CPT_EINVAL, "unknown option '%s'", key);
@@ -244,8 +246,13 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
 }
 
 // Whether the persistent extend kernel can run without any global-memory record or stack traffic.
+static bool variant_f32(const cpt_ctx* c) { return c->extend_variant >= 3; }
+static bool variant_cull(const cpt_ctx* c) { return c->extend_variant == 2 || c->extend_variant == 4; }
 static int scene_resident(const cpt_ctx* c) {
-    return c->has_scene && c->sc.n_nodes + c->sc.n_tris <= CPT_PW_CACHE_RECORDS_HOST && c->measured_height - 2 <= CPT_PW_STACK_LDS_HOST;
+    if (!c->has_scene || c->measured_height - 2 > CPT_PW_STACK_LDS_HOST) return 0;
+    // 128-byte slots the scene takes in the record cache (binary32 node records are half a slot each)
+    const long long slots = variant_f32(c) ? (c->sc.n_nodes + 1) / 2 + (long long)c->sc.n_tris : (long long)c->sc.n_nodes + c->sc.n_tris;
+    return slots <= CPT_PW_CACHE_RECORDS_HOST;
 }
 
 // Rays a wave claims at a time.  A claim stalls the wave for an atomic's round trip, so cheap rays (a
@@ -345,6 +352,18 @@ static int upload_shading(cpt_ctx* c, const cpt_scene_desc* s) {
     return CPT_OK;
 }
 
+// Binary32 copies of the node records (boxes rounded outwards) for the extend variants that test inner nodes in
+// binary32, derived on the device from the records in place.
+static int make_nodes32(cpt_ctx* c, int n_nodes) {
+    if (c->d_nodes32) { (void)hipFree(c->d_nodes32); c->d_nodes32 = nullptr; }
+    HIP_TRY(c, hipMalloc(&c->d_nodes32, 64 * (size_t)std::max(n_nodes, 1)));
+    launch_nodes32(c->stream, (const cpt_node*)c->d_nodes, n_nodes, c->d_nodes32);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->sc.nodes32 = c->d_nodes32;
+    return CPT_OK;
+}
+
 int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     if (!c || !s) return CPT_EINVAL;
     int measured = 0;
@@ -390,6 +409,8 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     c->n_tree_nodes = s->n_tree_nodes;
     c->tree_height = s->tree_height;
     c->measured_height = measured;
+    rc = make_nodes32(c, s->n_nodes);
+    if (rc != CPT_OK) return rc;
     c->has_scene = true;
     return CPT_OK;
 }
@@ -443,6 +464,8 @@ int cpt_build_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     c->n_tree_nodes = 2 * n - 1;
     c->tree_height = height;
     c->measured_height = height;
+    rc = make_nodes32(c, n - 1);
+    if (rc != CPT_OK) return rc;
     c->has_scene = true;
     return CPT_OK;
 }
@@ -494,6 +517,8 @@ int cpt_refit_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     (void)hipFree(d_order);
     if (e != hipSuccess) return fail(c, CPT_EHIP, "refit: %s", hipGetErrorString(e));
     rc = upload_shading(c, s);
+    if (rc != CPT_OK) return rc;
+    rc = make_nodes32(c, m);  // the boxes changed
     if (rc != CPT_OK) return rc;
     c->sc.cam = s->camera;
     return CPT_OK;
@@ -695,7 +720,7 @@ static int run_wavefront(cpt_ctx* c, const DParams& P, LaunchCfg L, cpt_ctx::Lan
 }
 
 static LaunchCfg launch_cfg(const cpt_ctx* c) {
-    return LaunchCfg{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), c->extend_variant == 2, c->pw_full_go, c->pw_leaf_go};
+    return LaunchCfg{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), variant_cull(c), variant_f32(c), c->pw_full_go, c->pw_leaf_go};
 }
 
 int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {

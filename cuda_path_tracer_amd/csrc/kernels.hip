@@ -249,6 +249,127 @@ __device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, cons
     return r;
 }
 
+struct Rec4f {  // a 64-byte binary32 node record as four 16-byte pieces
+    float4 p0, p1, p2, p3;
+};
+typedef float v4f_lds __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f_lds lds_v4f;
+__device__ __forceinline__ float4 lds_piece4(const lds_byte* p) {
+    v4f_lds v = *(const lds_v4f*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+// Cached binary32 node records start at byte 0 of the cache, 64 bytes each, their four pieces rotated by an XOR with
+// (index >> 2) & 3 so that lanes reading the same piece of different records spread over the LDS banks.
+template <bool RESIDENT>
+__device__ __forceinline__ Rec4f fetch_node32(const void* __restrict__ base, const lds_byte* cache, int cached, int idx) {
+    Rec4f r;
+    if (RESIDENT || idx < cached) {
+        const lds_byte* rec = cache + (uint32_t)idx * 64u;
+        const uint32_t z = ((uint32_t)idx >> 2) & 3u;
+        r.p0 = lds_piece4(rec + ((0u ^ z) << 4)); r.p1 = lds_piece4(rec + ((1u ^ z) << 4));
+        r.p2 = lds_piece4(rec + ((2u ^ z) << 4)); r.p3 = lds_piece4(rec + ((3u ^ z) << 4));
+    } else {
+        const float4* g = (const float4*)((const unsigned char*)base + (size_t)idx * 64);
+        r.p0 = g[0]; r.p1 = g[1]; r.p2 = g[2]; r.p3 = g[3];
+    }
+    return r;
+}
+
+// ---- binary32 node records ------------------------------------------------------------------------
+// What the reference's walk returns depends on the tree only through its leaves: a child box always contains
+// its descendants' boxes, correctly rounded subtraction and division are monotonic, so whenever a leaf's own box
+// passes the reference's slab test every box above it passes too.  The closest hit is therefore "the smallest t
+// (ties: smallest test_rank) over the triangles whose OWN leaf box passes the exact test and whose triangle test
+// hits", whatever inner boxes stand above them.  The F32 variant of the persistent kernel uses that: inner nodes
+// are tested in binary32 against outward-rounded copies of the boxes with error margins that make the test
+// conservative (it never rejects a box the exact test accepts), so it walks a superset of the reference's nodes
+// with a third of the arithmetic and half the record bytes, and every candidate leaf is then put to the exact
+// binary64 test of its own box (the bounds of the triangle's three vertices, exactly what the tree stores for a
+// leaf) before its triangle is tested.  Hits -- triangle, t bits -- are those of the exact walk; the visit set is
+// not the reference's, so the parity hooks and the default variant stay on the exact walk.
+struct __attribute__((aligned(64))) Node32 {
+    // pairs (left child, right child): lo.x, lo.y | lo.z, hi.x | hi.y, hi.z; each pair is one packed-fp32 operand
+    float lox[2], loy[2], loz[2], hix[2], hiy[2], hiz[2];
+    int32_t lref, rref;
+    int32_t pad_[2];
+};
+static_assert(sizeof(Node32) == 64, "Node32 is half a node record");
+__device__ __forceinline__ float f32_down(double x) {  // largest float <= x
+    float f = (float)x;
+    return ((double)f > x) ? nextafterf(f, -INFINITY) : f;
+}
+__device__ __forceinline__ float f32_up(double x) {  // smallest float >= x
+    float f = (float)x;
+    return ((double)f < x) ? nextafterf(f, INFINITY) : f;
+}
+__global__ void __launch_bounds__(CPT_BLOCK) k_nodes32(const cpt_node* __restrict__ nodes, int n, Node32* __restrict__ out) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const cpt_node nd = nodes[k];
+        Node32 r;
+        r.lox[0] = f32_down(nd.lbox[0]); r.lox[1] = f32_down(nd.rbox[0]);
+        r.loy[0] = f32_down(nd.lbox[1]); r.loy[1] = f32_down(nd.rbox[1]);
+        r.loz[0] = f32_down(nd.lbox[2]); r.loz[1] = f32_down(nd.rbox[2]);
+        r.hix[0] = f32_up(nd.lbox[3]); r.hix[1] = f32_up(nd.rbox[3]);
+        r.hiy[0] = f32_up(nd.lbox[4]); r.hiy[1] = f32_up(nd.rbox[4]);
+        r.hiz[0] = f32_up(nd.lbox[5]); r.hiz[1] = f32_up(nd.rbox[5]);
+        r.lref = nd.lref; r.rref = nd.rref;
+        r.pad_[0] = r.pad_[1] = 0;
+        out[k] = r;
+    }
+}
+
+// A ray as the binary32 box test wants it: per axis the reciprocal direction and the two additive constants of
+//   t(plane) = plane * r + c,   c = -(o * r) -/+ E,
+// one for the plane that is the near one for this ray's direction (lowered by E) and one for the far one (raised
+// by E).  E = 2^-20 (S |r| + |o r|), S = the largest plane magnitude in the scene, is sixteen times what the
+// roundings of r, of o * r and of c can amount to; the outward rounding of the planes is on the safe side by
+// itself, and the last rounding (of the fma) is covered by the relative slack of the final comparison.  An axis
+// whose products could overflow binary32, or on which the ray does not move, is left unconstrained (r = 0,
+// constants -inf / +inf): the exact test of the leaves decides.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct Ray32 {
+    float rx, ry, rz;
+    float clx, chx, cly, chy, clz, chz;  // constants for the lo plane and the hi plane of each axis
+};
+__device__ __forceinline__ void ray32_axis(double o, double r, float S, float& r32, float& c_lo, float& c_hi) {
+    // o * r once in binary64 (o and r can be large with a small product's worth of cancellation to come), the rest in
+    // binary32: its own roundings are relative 2^-24 of terms that E carries at 2^-20
+    const float orr = (float)(o * r), rf = (float)r;
+    const float ar = fabsf(rf), ao = fabsf(orr);
+    const bool ok = ar < 1e30f && ao < 1e30f && S * ar < 1e30f;  // also false for NaN
+    const float E = fmaf(fmaf(S, ar, ao), 9.5367431640625e-07f, 1e-30f);  // 2^-20 (S |r| + |o r|)
+    const float c_near = -orr - E, c_far = -orr + E;
+    r32 = ok ? rf : 0.0f;
+    c_lo = ok ? (rf >= 0 ? c_near : c_far) : -INFINITY;
+    c_hi = ok ? (rf >= 0 ? c_far : c_near) : INFINITY;
+}
+__device__ __forceinline__ Ray32 ray32_prepare(const dvec3& o, const SlabRay& sr, float S) {
+    Ray32 q;
+    ray32_axis(o.x, sr.r.x, S, q.rx, q.clx, q.chx);
+    ray32_axis(o.y, sr.r.y, S, q.ry, q.cly, q.chy);
+    ray32_axis(o.z, sr.r.z, S, q.rz, q.clz, q.chz);
+    return q;
+}
+// Both child boxes of a node at once (component 0: left child, 1: right child).  `keep` is false only when the
+// exact test is certain to miss; `enter` is a lower bound of the distance at which the ray enters the box.
+__device__ __forceinline__ void slab32_pair(v2f lox, v2f loy, v2f loz, v2f hix, v2f hiy, v2f hiz, const Ray32& q,
+                                            bool& keep_l, bool& keep_r, float& enter_l, float& enter_r) {
+    const v2f x1 = __builtin_elementwise_fma(lox, (v2f)(q.rx), (v2f)(q.clx)), x2 = __builtin_elementwise_fma(hix, (v2f)(q.rx), (v2f)(q.chx));
+    const v2f y1 = __builtin_elementwise_fma(loy, (v2f)(q.ry), (v2f)(q.cly)), y2 = __builtin_elementwise_fma(hiy, (v2f)(q.ry), (v2f)(q.chy));
+    const v2f z1 = __builtin_elementwise_fma(loz, (v2f)(q.rz), (v2f)(q.clz)), z2 = __builtin_elementwise_fma(hiz, (v2f)(q.rz), (v2f)(q.chz));
+#define CPT_SLAB32(K, KEEP, ENTER)                                                                    \
+    {                                                                                                 \
+        const float tn = fmaxf(fmaxf(fminf(x1[K], x2[K]), fminf(y1[K], y2[K])), fminf(z1[K], z2[K])); \
+        const float tf = fminf(fminf(fmaxf(x1[K], x2[K]), fmaxf(y1[K], y2[K])), fmaxf(z1[K], z2[K])); \
+        const float slack = fmaf(fabsf(tn) + fabsf(tf), 9.5367431640625e-07f, 1e-30f);                \
+        KEEP = !((tn - tf > slack) || (tf < 0.0f));                                                   \
+        ENTER = tn;                                                                                   \
+    }
+    CPT_SLAB32(0, keep_l, enter_l)
+    CPT_SLAB32(1, keep_r, enter_r)
+#undef CPT_SLAB32
+}
+
 //
 // CULL selects the fast mode: of two child boxes that are both hit the nearer one is walked first, and
 // a box the ray enters beyond the closest hit found so far (with a relative margin of 1e-6) is not
@@ -257,7 +378,8 @@ __device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, cons
 // RESIDENT: the whole scene is in the record cache and its tree is low enough for the LDS part of the node
 // stack, so the loop has no vector-memory record or spill path and none of the waits that come with
 // them; the only loads left are the rays.
-template <bool COUNT, bool CULL, bool RESIDENT>
+// F32: inner nodes through the conservative binary32 test, leaves through the exact test of their own box (see above).
+template <bool COUNT, bool CULL, bool RESIDENT, bool F32>
 __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStream in, HitBuf hit,
                                                               const uint32_t* __restrict__ counter, uint32_t* cursor, uint32_t cap,
                                                               uint32_t chunk, uint32_t refill_at, uint32_t leaf_go, uint32_t full_go, uint32_t* spill, unsigned long long* work) {
@@ -278,14 +400,39 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     }
 
     // fill the record cache: node records first, triangle records in what is left
-    const int cached_nodes = sc.n_nodes < CPT_PW_CACHE_RECORDS ? sc.n_nodes : CPT_PW_CACHE_RECORDS;
-    const int room = CPT_PW_CACHE_RECORDS - cached_nodes;
+    // (F32: 64-byte binary32 node records, twice as many per byte; triangle records start at the next 128-byte slot)
+    const int node_room = F32 ? CPT_PW_CACHE_RECORDS * 2 : CPT_PW_CACHE_RECORDS;
+    const int cached_nodes = sc.n_nodes < node_room ? sc.n_nodes : node_room;
+    const int tri_first = F32 ? (cached_nodes + 1) / 2 : cached_nodes;  // first 128-byte slot of the cached triangles
+    const int room = CPT_PW_CACHE_RECORDS - tri_first;
     const int cached_tris = sc.n_tris < room ? sc.n_tris : room;
-    for (int i = (int)threadIdx.x; i < (cached_nodes + cached_tris) * 8; i += CPT_PW_THREADS) {
-        int r = i >> 3, c = i & 7;
-        const unsigned char* src = r < cached_nodes ? (const unsigned char*)sc.nodes + (size_t)r * 128
-                                                    : (const unsigned char*)sc.tris + (size_t)(r - cached_nodes) * 128;
-        *(double2*)(s_cache + (size_t)r * 128 + (((uint32_t)c ^ (((uint32_t)r >> 1) & 7u)) << 4)) = *(const double2*)(src + c * 16);
+    if (F32) {
+        for (int i = (int)threadIdx.x; i < cached_nodes * 4; i += CPT_PW_THREADS) {
+            int r = i >> 2, c = i & 3;
+            *(float4*)(s_cache + (size_t)r * 64 + (((uint32_t)c ^ (((uint32_t)r >> 2) & 3u)) << 4)) =
+                *(const float4*)((const unsigned char*)sc.nodes32 + (size_t)r * 64 + c * 16);
+        }
+        for (int i = (int)threadIdx.x; i < cached_tris * 8; i += CPT_PW_THREADS) {
+            int r = tri_first + (i >> 3), c = i & 7;
+            *(double2*)(s_cache + (size_t)r * 128 + (((uint32_t)c ^ (((uint32_t)r >> 1) & 7u)) << 4)) =
+                *(const double2*)((const unsigned char*)sc.tris + (size_t)(i >> 3) * 128 + c * 16);
+        }
+    } else {
+        for (int i = (int)threadIdx.x; i < (cached_nodes + cached_tris) * 8; i += CPT_PW_THREADS) {
+            int r = i >> 3, c = i & 7;
+            const unsigned char* src = r < cached_nodes ? (const unsigned char*)sc.nodes + (size_t)r * 128
+                                                        : (const unsigned char*)sc.tris + (size_t)(r - cached_nodes) * 128;
+            *(double2*)(s_cache + (size_t)r * 128 + (((uint32_t)c ^ (((uint32_t)r >> 1) & 7u)) << 4)) = *(const double2*)(src + c * 16);
+        }
+    }
+    // the largest plane magnitude of the scene (the root's two child boxes contain everything): scale of the
+    // binary32 test's error margins
+    float scene_extent = 0.0f;
+    if (F32 && sc.n_nodes > 0) {
+        const double* b = (const double*)sc.nodes;
+        double m = 0.0;
+        for (int k = 0; k < 12; ++k) m = fmax(m, fabs(b[k]));
+        scene_extent = f32_up(m);
     }
     __syncthreads();
     const lds_byte* cache = (const lds_byte*)s_cache;
@@ -303,6 +450,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     uint32_t pos = 0;  // stream position of this lane's ray
     dvec3 o = dv(0, 0, 0), d = dv(0, 0, 1);
     SlabRay sr = slab_prepare(o, dv(1, 1, 1));
+    Ray32 q32 = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double best_t = -1.0;
     int best_tri = -1;
     uint32_t best_rank = 0xFFFFFFFFu;
@@ -334,6 +482,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 pos = chunk_pos + mine;  // idle lanes take consecutive positions: one contiguous run per refill
                 load_ray_geometry(in, pos, o, d);
                 sr = slab_prepare(o, d);
+                if (F32) q32 = ray32_prepare(o, sr, scene_extent);
                 best_t = -1.0;
                 best_tri = -1;
                 best_rank = 0xFFFFFFFFu;
@@ -366,16 +515,29 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 if (lane == 0 && boxing) box_passes++;
             }
             if (node >= 0 && lp <= CPT_PW_LEAF_CAP - 2) {
-                Rec7 r = fetch_record<RESIDENT>(sc.nodes, cache, 0, cached_nodes, node);
-                int2 refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));  // lref, rref
-                bool sure_l, sure_r;
+                int2 refs;  // lref, rref
+                bool hl, hr;
                 double enter_l, enter_r;
-                bool hl = slab_filtered(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, sr, sure_l, enter_l);
-                bool hr = slab_filtered(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, sr, sure_r, enter_r);
-                if (sr.exact_only || !(sure_l && sure_r)) {
-                    if (COUNT) exact++;
-                    hl = slab_hit(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, d, enter_l);
-                    hr = slab_hit(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, d, enter_r);
+                if (F32) {
+                    const Rec4f r = fetch_node32<RESIDENT>(sc.nodes32, cache, cached_nodes, node);
+                    refs = make_int2(__float_as_int(r.p3.x), __float_as_int(r.p3.y));
+                    float el, er;
+                    v2f lox = {r.p0.x, r.p0.y}, loy = {r.p0.z, r.p0.w}, loz = {r.p1.x, r.p1.y};
+                    v2f hix = {r.p1.z, r.p1.w}, hiy = {r.p2.x, r.p2.y}, hiz = {r.p2.z, r.p2.w};
+                    slab32_pair(lox, loy, loz, hix, hiy, hiz, q32, hl, hr, el, er);
+                    enter_l = (double)el;
+                    enter_r = (double)er;
+                } else {
+                    Rec7 r = fetch_record<RESIDENT>(sc.nodes, cache, 0, cached_nodes, node);
+                    refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));
+                    bool sure_l, sure_r;
+                    hl = slab_filtered(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, sr, sure_l, enter_l);
+                    hr = slab_filtered(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, sr, sure_r, enter_r);
+                    if (sr.exact_only || !(sure_l && sure_r)) {
+                        if (COUNT) exact++;
+                        hl = slab_hit(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, d, enter_l);
+                        hr = slab_hit(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, d, enter_r);
+                    }
                 }
                 if (CULL) {
                     if (best_t >= 0) {
@@ -420,12 +582,28 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 if (lp > 0) {
                     --lp;
                     int tri = (int)my_leaves[lp * CPT_WAVE];
-                    Rec7 q = fetch_record<RESIDENT>(sc.tris, cache, cached_nodes, cached_tris, tri);
+                    Rec7 q = fetch_record<RESIDENT>(sc.tris, cache, tri_first, cached_tris, tri);
                     uint32_t flags = (uint32_t)__double2hiint(q.p6.x), rank = (uint32_t)__double2loint(q.p6.y);
+                    bool gate = true;
+                    if (F32 && sc.n_nodes > 0) {  // (a one-triangle scene has no boxes at all) the exact test of the leaf's own box: the bounds of the three vertices (reference: src/scene/bvh.cpp:128-146)
+                        const double lx = fmin(fmin(q.p0.x, q.p1.y), q.p3.x), hx = fmax(fmax(q.p0.x, q.p1.y), q.p3.x);
+                        const double ly = fmin(fmin(q.p0.y, q.p2.x), q.p3.y), hy = fmax(fmax(q.p0.y, q.p2.x), q.p3.y);
+                        const double lz = fmin(fmin(q.p1.x, q.p2.y), q.p4.x), hz = fmax(fmax(q.p1.x, q.p2.y), q.p4.x);
+                        bool sure;
+                        double enter;
+                        gate = slab_filtered(lx, ly, lz, hx, hy, hz, o, sr, sure, enter);
+                        if (sr.exact_only || !sure) {
+                            if (COUNT) exact++;
+                            gate = slab_hit(lx, ly, lz, hx, hy, hz, o, d, enter);
+                        }
+                        if (CULL && best_t >= 0 && enter > best_t * 1.000001 + 1e-9) gate = false;
+                    }
                     double t;
-                    if (COUNT) tris++;
-                    if (tri_hit_regs(q.p0, q.p1, q.p2, q.p3, q.p4, q.p5, flags, o, d, t)) {
-                        if (best_t < 0 || t < best_t || (t == best_t && rank < best_rank)) { best_t = t; best_tri = tri; best_rank = rank; }
+                    if (gate) {
+                        if (COUNT) tris++;
+                        if (tri_hit_regs(q.p0, q.p1, q.p2, q.p3, q.p4, q.p5, flags, o, d, t)) {
+                            if (best_t < 0 || t < best_t || (t == best_t && rank < best_rank)) { best_t = t; best_tri = tri; best_rank = rank; }
+                        }
                     }
                 }
             }
@@ -683,6 +861,11 @@ void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, con
     int g = grid_for((long long)batch_n * P.n_pix_slots, L.max_blocks);
     hipLaunchKernelGGL(k_generate, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, out, col, batch_s0, batch_n);
 }
+void launch_nodes32(hipStream_t st, const cpt_node* d_nodes, int n_nodes, void* d_nodes32) {
+    if (n_nodes < 1) return;
+    int g = (n_nodes + CPT_BLOCK - 1) / CPT_BLOCK;
+    hipLaunchKernelGGL(k_nodes32, dim3(g > 4096 ? 4096 : g), dim3(CPT_BLOCK), 0, st, d_nodes, n_nodes, (Node32*)d_nodes32);
+}
 void launch_dense_counts(const LaunchCfg& L, uint32_t* counts, uint32_t n, uint32_t cap) {
     hipLaunchKernelGGL(k_dense_counts, dim3(1), dim3(64), 0, L.stream, counts, n, cap);
 }
@@ -695,21 +878,29 @@ void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, co
 void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
                       uint32_t cap, uint32_t* cursor, uint32_t* spill, unsigned long long* work) {
     int g = L.pw_blocks;
-#define CPT_PW_LAUNCH(COUNT, CULL, RES)                                                                                  \
-    hipLaunchKernelGGL((k_extend_pw<COUNT, CULL, RES>), dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, \
+#define CPT_PW_LAUNCH(COUNT, CULL, RES, F32)                                                                                  \
+    hipLaunchKernelGGL((k_extend_pw<COUNT, CULL, RES, F32>), dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, \
                        cursor, cap, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go,                       \
                        (uint32_t)L.pw_full_go, spill, work)
     const bool resident = L.pw_resident != 0;
-    const int which = (work ? 4 : 0) | (L.pw_cull ? 2 : 0) | (resident ? 1 : 0);
+    const int which = (L.pw_f32 ? 8 : 0) | (work ? 4 : 0) | (L.pw_cull ? 2 : 0) | (resident ? 1 : 0);
     switch (which) {
-        case 0: CPT_PW_LAUNCH(false, false, false); break;
-        case 1: CPT_PW_LAUNCH(false, false, true); break;
-        case 2: CPT_PW_LAUNCH(false, true, false); break;
-        case 3: CPT_PW_LAUNCH(false, true, true); break;
-        case 4: CPT_PW_LAUNCH(true, false, false); break;
-        case 5: CPT_PW_LAUNCH(true, false, true); break;
-        case 6: CPT_PW_LAUNCH(true, true, false); break;
-        default: CPT_PW_LAUNCH(true, true, true); break;
+        case 0: CPT_PW_LAUNCH(false, false, false, false); break;
+        case 1: CPT_PW_LAUNCH(false, false, true, false); break;
+        case 2: CPT_PW_LAUNCH(false, true, false, false); break;
+        case 3: CPT_PW_LAUNCH(false, true, true, false); break;
+        case 4: CPT_PW_LAUNCH(true, false, false, false); break;
+        case 5: CPT_PW_LAUNCH(true, false, true, false); break;
+        case 6: CPT_PW_LAUNCH(true, true, false, false); break;
+        case 7: CPT_PW_LAUNCH(true, true, true, false); break;
+        case 8: CPT_PW_LAUNCH(false, false, false, true); break;
+        case 9: CPT_PW_LAUNCH(false, false, true, true); break;
+        case 10: CPT_PW_LAUNCH(false, true, false, true); break;
+        case 11: CPT_PW_LAUNCH(false, true, true, true); break;
+        case 12: CPT_PW_LAUNCH(true, false, false, true); break;
+        case 13: CPT_PW_LAUNCH(true, false, true, true); break;
+        case 14: CPT_PW_LAUNCH(true, true, false, true); break;
+        default: CPT_PW_LAUNCH(true, true, true, true); break;
     }
 #undef CPT_PW_LAUNCH
 }

@@ -57,6 +57,7 @@ struct DScene {
     const cpt_node* __restrict__ nodes;
     const cpt_tri* __restrict__ tris;       // intersection records (extend)
     const ShadeRec* __restrict__ shade;     // shading records (shade), one per triangle
+    const void* __restrict__ nodes32;       // 64-byte binary32 copies of the node records, boxes rounded outwards (extend variants 3 and 4)
     cpt_camera cam;
     int n_nodes, n_tris;
 };
@@ -142,12 +143,14 @@ struct LaunchCfg {
     int pw_refill;   // a wave refills when at least this many of its lanes are idle
     int pw_resident; // 1: scene fits the LDS record cache and its node stack fits the LDS entries (checked by the host)
     int pw_cull;     // 1: nearest-first walk with closest-hit culling (fast mode), 0: the reference's visit set
+    int pw_f32;      // 1: inner nodes through the conservative binary32 test, leaves through the exact test of their own box
     int pw_full_go;  // ... or when at least this many lanes cannot expand a node because their parked-leaf list is full
     int pw_leaf_go;  // a wave runs its triangle phase when at least this many lanes have a parked leaf
 };
 
 void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& out, const Radiance& col,
                      int batch_s0, int batch_n);
+void launch_nodes32(hipStream_t st, const cpt_node* d_nodes, int n_nodes, void* d_nodes32);
 void launch_dense_counts(const LaunchCfg& L, uint32_t* counts, uint32_t n, uint32_t cap);
 void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
                    uint32_t cap, long long max_entries, unsigned long long* work);

@@ -155,7 +155,12 @@ int cpt_set_stream(cpt_ctx* ctx, void* hip_stream);
  * does not depend on it), "max_blocks" (grid cap of the grid-stride kernels, default 8 per CU),
  * "extend_variant" (1: persistent waves with an LDS record cache, default; 0: one ray per thread;
  * 2: as 1 but walking the nearer child first and skipping boxes entered beyond the closest hit so
- * far -- a fast mode that returns the same hits without reproducing the reference's visit set),
+ * far -- a fast mode that returns the same hits without reproducing the reference's visit set;
+ * 3: as 1 but inner nodes are tested in binary32 against outward-rounded boxes with margins that make the test
+ * conservative, and every candidate leaf is then put to the exact binary64 test of its own box before its triangle
+ * is tested: because a box that contains a leaf's box can never fail the reference's test when the leaf's box
+ * passes it, the closest hits are exactly those of variant 1, from a slightly larger visit set and a third less
+ * arithmetic per node; 4: as 3 with the nearest-first walk and culling of 2),
  * "pw_blocks" / "pw_chunk" (workgroups of the persistent extend kernel / rays a wave claims per
  * atomic, 0 = chosen from the scene size),
  * "pw_refill" / "pw_leaf_go" / "pw_full_go" (a wave of that kernel refills when this many lanes are

@@ -136,7 +136,7 @@ def compare_with_oracle_on_same_tree(gpu, orc, boxes, n_rays, seed):
             assert np.array_equal(got[key], want[key]), key
         assert np.array_equal(bits(got["t"]), bits(want["t"]))
         try:
-            for variant in (1, 0, 2):
+            for variant in (1, 0, 2, 3, 4):
                 gpu.set_option("extend_variant", variant)
                 tri, t = gpu.extend_rays(o, d)
                 assert np.array_equal(tri, want["prim"]) and np.array_equal(bits(t), bits(want["t"])), "variant %d" % variant

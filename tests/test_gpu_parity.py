@@ -292,7 +292,7 @@ def test_pipeline_extend_kernel_on_explicit_rays_bit_exact(name, gpu_scene, orac
     try:
         for (o, d, expect_fallback) in [(o1, d1, False), (o2, d2, True)]:
             want = orc.trace(o, d)
-            for variant in (1, 0, 2):
+            for variant in (1, 0, 2, 3, 4):
                 g.set_option("extend_variant", variant)
                 g.reset_stats()
                 g.set_instrumentation(time_kernels=False, count_work=True)
@@ -302,6 +302,16 @@ def test_pipeline_extend_kernel_on_explicit_rays_bit_exact(name, gpu_scene, orac
                 assert np.array_equal(bits(t), bits(want["t"])), "hit distances differ (variant %d)" % variant
                 if variant == 2:  # the culling walk may skip work, never add any
                     assert st["node_steps"] <= int(want["node_steps"].sum())
+                    continue
+                if variant == 3:
+                    # inner nodes through the conservative binary32 test: a superset of the reference's nodes, but only
+                    # just (the margins are a few parts in a million); every leaf goes through the exact test of its own
+                    # box, so the triangles tested are exactly the reference's
+                    assert int(want["node_steps"].sum()) <= st["node_steps"] <= 1.02 * int(want["node_steps"].sum()) + 64
+                    assert st["tri_tests"] == int(want["tri_tests"].sum())
+                    continue
+                if variant == 4:  # the same with culling: fewer triangles, never more
+                    assert st["tri_tests"] <= int(want["tri_tests"].sum())
                     continue
                 assert st["node_steps"] == int(want["node_steps"].sum())
                 assert st["tri_tests"] == int(want["tri_tests"].sum())
@@ -435,7 +445,7 @@ def test_every_pipeline_variant_gives_the_same_image(gpu_scene):
     w, h, spp, depth = 96, 64, 6, 8
     images = []
     try:
-        for ev in (0, 1, 2):  # 2 = nearest-first with culling: other visit sets, the same closest hits
+        for ev in (0, 1, 2, 3, 4):  # 2 = nearest-first with culling, 3 / 4 = binary32 inner nodes without / with culling: other visit sets, the same closest hits
             g.set_option("extend_variant", ev)
             acc = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
             g.render_into(acc.data_ptr(), g.params(w, h, 0, spp, depth))
@@ -584,7 +594,7 @@ def test_bench_two_ranks_on_one_gpu(scaling, launcher):
     from conftest import ROOT
     env = dict(os.environ, CPT_BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
-    tail = ["--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "cornell2", "--extra", "none", "--no-cpu-baseline",
+    tail = ["--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "cornell2", "--extra", "none", "--no-cpu-baseline", "--no-fast-modes",
             "--scaling", "weak" if scaling == "weak" else "strong"]
     if launcher == "torchrun":
         with socket.socket() as s:
@@ -657,7 +667,7 @@ def test_deep_stacks_spill_past_the_lds_entries(tmp_path, gpu, oracle):
     want = _compare_trace(gpu, orc, o, d, bitmap=False)
     assert int(want["max_stack"].max()) > 12
     try:
-        for variant in (1, 0, 2):
+        for variant in (1, 0, 2, 3, 4):
             gpu.set_option("extend_variant", variant)
             tri, t = gpu.extend_rays(o, d)
             assert np.array_equal(tri, want["prim"]) and np.array_equal(bits(t), bits(want["t"])), variant

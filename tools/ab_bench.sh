@@ -9,7 +9,7 @@ mkdir -p gpurun_out/ab
 for lib in "${libs[@]}"; do
   tag=$(basename "$lib" .so)
   if [ "$lib" == "default" ]; then unset CPT_AMD_LIBRARY; else export CPT_AMD_LIBRARY="$lib"; fi
-  timeout -k 10 300 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > gpurun_out/ab/$tag.json 2> gpurun_out/ab/$tag.err || { echo "$tag FAILED"; tail -5 gpurun_out/ab/$tag.err; exit 1; }
+  timeout -k 10 300 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fast-modes "$@" > gpurun_out/ab/$tag.json 2> gpurun_out/ab/$tag.err || { echo "$tag FAILED"; tail -5 gpurun_out/ab/$tag.err; exit 1; }
   python3 - "$tag" gpurun_out/ab/$tag.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
