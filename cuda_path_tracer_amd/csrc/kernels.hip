@@ -217,7 +217,9 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
 #define CPT_PW_STACK_LDS 12
 static_assert(CPT_PW_CACHE_RECORDS == CPT_PW_CACHE_RECORDS_HOST, "record cache size must match the host's chunk choice");
 static_assert(CPT_PW_STACK_LDS == CPT_PW_STACK_LDS_HOST, "stack split must match the spill buffer sizing");
+#ifndef CPT_PW_BOX_REPEAT
 #define CPT_PW_BOX_REPEAT 3   // node expansions per lane and loop turn
+#endif
 #define CPT_PW_LEAF_CAP 10    // parked leaves per lane (a node expansion adds at most two)
 
 struct Rec7 {  // the first seven 16-byte pieces of a 128-byte record

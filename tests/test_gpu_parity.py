@@ -816,3 +816,28 @@ def test_converged_image_against_reference_showcase_renders(scene, depth, rms_li
     assert rms < rms_limit, rms
     assert abs(level - ref.mean()) < 0.5, (level, ref.mean())
     assert fit(depth - 1, 2048)[0] > 1.5 * rms and fit(depth + 1, 2048)[0] > 1.3 * rms
+
+
+def test_switching_streams_is_a_fence(gpu_scene):
+    """cpt_set_stream orders the new stream after what the context queued on the old one: two renders into one buffer,
+    the second on another stream with no synchronisation in between, add up to the single render of both sample
+    ranges (the streams, counters and scratch of the context are shared by the two)."""
+    import torch
+    g = gpu_scene("cornell-box2-transmissive")
+    w, h, depth = 160, 120, 6
+    want = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+    g.render_into(want.data_ptr(), g.params(w, h, 0, 24, depth))
+    g.synchronize()
+    got = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    try:
+        g.set_stream(a.cuda_stream)
+        g.render_into(got.data_ptr(), g.params(w, h, 0, 13, depth))
+        g.set_stream(b.cuda_stream)
+        g.render_into(got.data_ptr(), g.params(w, h, 13, 24, depth))
+        g.synchronize()  # waits for stream b, which was ordered after stream a by the switch
+        a.synchronize()
+    finally:
+        g.set_stream(None)
+    assert torch.equal(want.view(torch.int64), got.view(torch.int64))
