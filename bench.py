@@ -168,7 +168,11 @@ class Bench:
         self.local_rank = local_rank
         torch.cuda.set_device(local_rank)
         self.ranks_seen = 1
-        if self.world > 1:
+        # CPT_BENCH_FORCE_DIST=1 (under torch.distributed.run with one rank): bring the process group up and send every
+        # reduce through it anyway -- what a one-GPU box can rehearse of the RCCL path (communicator set-up, an fp64 SUM
+        # reduce of a device tensor)
+        self.distributed = self.world > 1 or (bool(os.environ.get("CPT_BENCH_FORCE_DIST")) and "WORLD_SIZE" in os.environ)
+        if self.distributed:
             from cuda_path_tracer_amd.dist import reduce_radiance
             if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -176,7 +180,7 @@ class Bench:
                 dist.init_process_group(self.backend)
             # communicator set-up (seconds for RCCL) must never land in a timed region, whatever --warmup says
             probe = torch.ones(1, dtype=torch.float64, device="cuda")
-            reduce_radiance(probe, dst=0)
+            reduce_radiance(probe, dst=0, single_rank_too=True)
             torch.cuda.synchronize()
             self.ranks_seen = dist.get_world_size()
             if self.rank == 0 and int(round(float(probe.item()))) != self.world:
@@ -193,7 +197,7 @@ class Bench:
 
     def fence(self):
         self.torch.cuda.synchronize()
-        if self.world > 1:
+        if self.distributed:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
@@ -241,7 +245,7 @@ class Bench:
                     r.render_into(acc.data_ptr(), r.params(w, h, share["sample_begin"], share["sample_end"], wl["depth"], mode=mode,
                                                            tile_begin=share["tile_begin"], tile_count=share["tile_count"], **extra))
                 if collective:
-                    reduce_radiance(acc, dst=0)
+                    reduce_radiance(acc, dst=0, single_rank_too=self.distributed)
                 if rank == 0:
                     r.tonemap_into(acc.data_ptr(), w, h, total_spp, rgb.data_ptr())
 
@@ -255,7 +259,7 @@ class Bench:
         self.fence()
         elapsed = time.perf_counter() - t0
         self.say("%s: timed steps done in %.3f s" % (key, elapsed))
-        if world > 1:
+        if self.distributed:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -270,7 +274,7 @@ class Bench:
             r.close()
         del renderers
         torch.cuda.empty_cache()
-        if world > 1:
+        if self.distributed:
             dist.barrier()  # the other ranks wait here while rank 0 runs its instrumented steps
         return rec
 
@@ -414,12 +418,12 @@ def main():
                           "paths_per_step": head["paths_per_step"],
                           "sharding": ("spp range per rank (%s scaling), fp64 radiance reduce to rank 0" % args.scaling)
                                       if world > 1 else "single GPU",
-                          "rccl_ranks": b.ranks_seen, "backend": b.backend if world > 1 else None},
+                          "rccl_ranks": b.ranks_seen, "backend": b.backend if b.distributed else None},
                "roofline": head["roofline"], "workloads": extras, "fast_modes": fast}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)
-    if b.world > 1:
+    if b.distributed:
         b.dist.barrier()
         b.dist.destroy_process_group()
 

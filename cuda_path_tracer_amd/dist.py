@@ -51,11 +51,12 @@ def shard(rank, world, spp, width, height, scaling="strong"):
     return dict(sample_begin=0, sample_end=spp, tile_begin=tiles[0], tile_count=tiles[1])
 
 
-def reduce_radiance(accum, dst=0, group=None):
+def reduce_radiance(accum, dst=0, group=None, single_rank_too=False):
     """Sum every rank's accumulation tensor into rank `dst` (in place there).  One collective of
-    w*h*3 float64 per render."""
+    w*h*3 float64 per render.  With one rank there is nothing to add and no collective is issued, unless
+    single_rank_too asks for it (a one-GPU rehearsal of the RCCL call itself)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or single_rank_too):
         if accum.is_cuda and dist.get_backend(group) == "gloo":
             # gloo reduces host tensors only: stage through the host (rehearsals on boxes without RCCL peers)
             host = accum.cpu()

@@ -621,6 +621,31 @@ def test_bench_two_ranks_on_one_gpu(scaling, launcher):
     assert 0 < out["roofline"]["frac"] <= 1 and out["roofline"]["bound"] == "fp64_valu_issue"
 
 
+def test_bench_one_rank_through_rccl():
+    """What one GPU can rehearse of the RCCL path: bench.py under the launcher with a single rank and
+    CPT_BENCH_FORCE_DIST=1 brings the nccl (= RCCL) process group up on the device and sends the warm-up reduce, every
+    step's fp64 radiance reduce, the timing all-reduce and the barriers through it."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CPT_BENCH_FORCE_DIST="1")
+    env.pop("CPT_BENCH_BACKEND", None)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload",
+           "cornell2", "--extra", "none", "--no-cpu-baseline", "--no-fast-modes"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["config"]["backend"] == "nccl" and out["config"]["rccl_ranks"] == 1 and out["value"] > 0
+
+
 def test_bench_fails_when_a_rank_fails():
     """A rank that dies makes the self-launched bench exit non-zero and print no result line (here every rank
     refuses an option the library does not know)."""
