@@ -57,6 +57,10 @@ struct cpt_ctx {
 
     void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_nodes32 = nullptr;
     double scene_extent = 0.0;  // largest box-plane magnitude (of the root's two child boxes)
+    // Triangles are kept on the device in an order of the library's own when the scene does not fit the extend kernel's
+    // record cache whole (largest bounding box first: the cached prefix then holds the triangles most rays test);
+    // tri_ext[internal] = the caller's index, tri_int the inverse.  Empty: the caller's order.
+    std::vector<int32_t> tri_ext, tri_int;
     DScene sc{};
     bool has_scene = false;
     int n_tree_nodes = 0, tree_height = 0, measured_height = 0;
@@ -275,6 +279,65 @@ static int validate_triangles(cpt_ctx* c, const cpt_scene_desc* s) {
     return CPT_OK;
 }
 
+// The scene as the device will hold it.  When triangles and nodes do not all fit the persistent extend kernel's LDS
+// record cache, the cache holds a prefix of each array; node records already come top of the tree first, and the
+// triangles are put largest bounding box first here (a ray tests a leaf's triangle when it pierces the leaf's box, so
+// the few triangles with scene-sized boxes -- walls, floors -- take most of the tests: on the dragon scene the eight
+// largest take over 90 % of them).  Hit records, shading records and tie-break ranks use the internal index; the entry
+// points that report triangle indices translate back.
+struct OrderedScene {
+    std::vector<cpt_tri> tris;
+    std::vector<cpt_tri_normals> normals;
+    std::vector<cpt_node> nodes;
+    cpt_scene_desc desc;
+};
+static double box_area_of(const cpt_tri& t) {
+    double e[3];
+    for (int k = 0; k < 3; ++k) e[k] = std::max(t.a[k], std::max(t.b[k], t.c[k])) - std::min(t.a[k], std::min(t.b[k], t.c[k]));
+    return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+}
+// new_order: choose the order afresh (upload, build); otherwise apply the one in place (refit).  `out` receives the
+// description to use from here on, which points into `os` or is *s itself when the caller's order stands.
+static const cpt_scene_desc* order_scene(cpt_ctx* c, const cpt_scene_desc* s, bool new_order, bool with_nodes, OrderedScene& os) {
+    const int n = s->n_tris;
+    if (new_order) {
+        c->tri_ext.clear();
+        c->tri_int.clear();
+        const long long n_nodes = with_nodes ? s->n_nodes : (long long)n - 1;
+        if (n_nodes + n > CPT_PW_CACHE_RECORDS_HOST) {
+            std::vector<double> area((size_t)n);
+            for (int i = 0; i < n; ++i) area[(size_t)i] = box_area_of(s->tris[i]);
+            c->tri_ext.resize((size_t)n);
+            for (int i = 0; i < n; ++i) c->tri_ext[(size_t)i] = i;
+            std::stable_sort(c->tri_ext.begin(), c->tri_ext.end(), [&](int32_t a, int32_t b) {
+                const double x = area[(size_t)a], y = area[(size_t)b];
+                return (x > y) || (x != x && y == y);  // NaN areas (non-finite vertices are refused elsewhere) first, deterministically
+            });
+            c->tri_int.resize((size_t)n);
+            for (int i = 0; i < n; ++i) c->tri_int[(size_t)c->tri_ext[(size_t)i]] = i;
+        }
+    }
+    if (c->tri_ext.empty() || (int)c->tri_ext.size() != n) return s;
+    os.tris.resize((size_t)n);
+    os.normals.resize((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        os.tris[(size_t)i] = s->tris[c->tri_ext[(size_t)i]];
+        os.normals[(size_t)i] = s->tri_normals[c->tri_ext[(size_t)i]];
+    }
+    os.desc = *s;
+    os.desc.tris = os.tris.data();
+    os.desc.tri_normals = os.normals.data();
+    if (with_nodes && s->n_nodes > 0) {
+        os.nodes.assign(s->nodes, s->nodes + s->n_nodes);
+        for (cpt_node& nd : os.nodes) {
+            if (nd.lref < 0) nd.lref = ~c->tri_int[(size_t)(~nd.lref)];
+            if (nd.rref < 0) nd.rref = ~c->tri_int[(size_t)(~nd.rref)];
+        }
+        os.desc.nodes = os.nodes.data();
+    }
+    return &os.desc;
+}
+
 static int validate_scene(cpt_ctx* c, const cpt_scene_desc* s, int* measured_height) {
     int rc = validate_triangles(c, s);
     if (rc != CPT_OK) return rc;
@@ -369,6 +432,8 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     int measured = 0;
     int rc = validate_scene(c, s, &measured);
     if (rc != CPT_OK) return rc;
+    OrderedScene ordered;
+    s = order_scene(c, s, true, true, ordered);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_scene(c);
@@ -427,6 +492,8 @@ int cpt_build_scene(cpt_ctx* c, const cpt_scene_desc* s) {
         for (int k = 0; k < 3; ++k)
             if (!std::isfinite(s->tris[i].a[k]) || !std::isfinite(s->tris[i].b[k]) || !std::isfinite(s->tris[i].c[k]))
                 return fail(c, CPT_EINVAL, "triangle %d: vertex is not finite", i);
+    OrderedScene ordered;
+    s = order_scene(c, s, true, false, ordered);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_scene(c);
@@ -481,6 +548,8 @@ int cpt_refit_scene(cpt_ctx* c, const cpt_scene_desc* s) {
         for (int k = 0; k < 3; ++k)
             if (!std::isfinite(s->tris[i].a[k]) || !std::isfinite(s->tris[i].b[k]) || !std::isfinite(s->tris[i].c[k]))
                 return fail(c, CPT_EINVAL, "triangle %d: vertex is not finite", i);
+    OrderedScene ordered;
+    s = order_scene(c, s, false, false, ordered);  // the order chosen when the tree in place was made
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     // levels of the records of the tree in place (children are stored after their parents, so one forward pass
@@ -535,12 +604,17 @@ int cpt_download_tree(cpt_ctx* c, cpt_node* h_nodes, int32_t node_capacity, uint
         if (node_capacity < c->sc.n_nodes) return fail(c, CPT_EINVAL, "node buffer holds %d records, the tree has %d", node_capacity, c->sc.n_nodes);
         if (c->sc.n_nodes > 0)
             HIP_TRY(c, hipMemcpy(h_nodes, c->d_nodes, sizeof(cpt_node) * (size_t)c->sc.n_nodes, hipMemcpyDeviceToHost));
+        if (!c->tri_ext.empty())  // leaves name triangles by the caller's indices
+            for (int k = 0; k < c->sc.n_nodes; ++k) {
+                if (h_nodes[k].lref < 0) h_nodes[k].lref = ~c->tri_ext[(size_t)(~h_nodes[k].lref)];
+                if (h_nodes[k].rref < 0) h_nodes[k].rref = ~c->tri_ext[(size_t)(~h_nodes[k].rref)];
+            }
     }
     if (h_test_rank) {
         if (tri_capacity < c->sc.n_tris) return fail(c, CPT_EINVAL, "rank buffer holds %d entries, the scene has %d triangles", tri_capacity, c->sc.n_tris);
         std::vector<cpt_tri> tris((size_t)c->sc.n_tris);
         HIP_TRY(c, hipMemcpy(tris.data(), c->d_tris, sizeof(cpt_tri) * tris.size(), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < tris.size(); ++i) h_test_rank[i] = tris[i].test_rank;
+        for (size_t i = 0; i < tris.size(); ++i) h_test_rank[c->tri_ext.empty() ? i : (size_t)c->tri_ext[i]] = tris[i].test_rank;
     }
     return CPT_OK;
 }
@@ -972,6 +1046,9 @@ int cpt_trace_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, 
     if (h_counts) HIP_TRY(c, hipMemcpyAsync(h_counts, cnt.p, N * 16, hipMemcpyDeviceToHost, c->stream));
     if (h_bitmap) HIP_TRY(c, hipMemcpyAsync(h_bitmap, bm.p, N * (size_t)stride, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!c->tri_ext.empty())
+        for (size_t i = 0; i < N; ++i)
+            if (h_tri[i] >= 0) h_tri[i] = c->tri_ext[(size_t)h_tri[i]];
     return CPT_OK;
 }
 
@@ -1007,7 +1084,10 @@ int cpt_extend_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d,
     std::vector<HitRec> recs(N);
     HIP_TRY(c, hipMemcpyAsync(recs.data(), ln.H.rec, N * sizeof(HitRec), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i < N; ++i) { h_t[i] = recs[i].t; h_tri[i] = recs[i].tri; }
+    for (size_t i = 0; i < N; ++i) {
+        h_t[i] = recs[i].t;
+        h_tri[i] = (recs[i].tri >= 0 && !c->tri_ext.empty()) ? c->tri_ext[(size_t)recs[i].tri] : recs[i].tri;
+    }
     if (work) return collect_work(c);
     return CPT_OK;
 }

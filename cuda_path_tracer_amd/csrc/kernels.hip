@@ -221,6 +221,9 @@ static_assert(CPT_PW_STACK_LDS == CPT_PW_STACK_LDS_HOST, "stack split must match
 #define CPT_PW_BOX_REPEAT 3   // node expansions per lane and loop turn
 #endif
 #define CPT_PW_LEAF_CAP 10    // parked leaves per lane (a node expansion adds at most two)
+#ifndef CPT_PW_HOT_TRIS
+#define CPT_PW_HOT_TRIS 32    // record-cache slots kept for triangles when the node records alone would fill it
+#endif
 
 struct Rec7 {  // the first seven 16-byte pieces of a 128-byte record
     double2 p0, p1, p2, p3, p4, p5, p6;
@@ -403,7 +406,11 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
 
     // fill the record cache: node records first, triangle records in what is left
     // (F32: 64-byte binary32 node records, twice as many per byte; triangle records start at the next 128-byte slot)
-    const int node_room = F32 ? CPT_PW_CACHE_RECORDS * 2 : CPT_PW_CACHE_RECORDS;
+    // A scene that does not fit whole keeps CPT_PW_HOT_TRIS slots for its first triangles, which the library has put
+    // largest bounding box first: those few take most of the triangle tests.
+    const bool fits = (F32 ? (sc.n_nodes + 1) / 2 : sc.n_nodes) + sc.n_tris <= CPT_PW_CACHE_RECORDS;
+    const int tri_reserve = fits ? 0 : (sc.n_tris < CPT_PW_HOT_TRIS ? sc.n_tris : CPT_PW_HOT_TRIS);
+    const int node_room = F32 ? (CPT_PW_CACHE_RECORDS - tri_reserve) * 2 : CPT_PW_CACHE_RECORDS - tri_reserve;
     const int cached_nodes = sc.n_nodes < node_room ? sc.n_nodes : node_room;
     const int tri_first = F32 ? (cached_nodes + 1) / 2 : cached_nodes;  // first 128-byte slot of the cached triangles
     const int room = CPT_PW_CACHE_RECORDS - tri_first;
