@@ -13,7 +13,7 @@ from conftest import scene_path
 pytestmark = pytest.mark.gpu
 
 SCENES = ["cornell-box2", "cornell-box2-specular", "cornell-box2-transmissive", "teapot-trans", "dragon-spec",
-          "dragon-trans"]
+          "dragon-trans", "3-dragon-spec"]
 
 
 def bits(a):
@@ -79,7 +79,7 @@ def test_primary_rays_hit_ids_and_visit_sets_bit_exact(name, gpu_scene, oracle_s
     assert (b["prim"] >= 0).mean() > 0.5
 
 
-@pytest.mark.parametrize("name", ["cornell-box2-transmissive", "dragon-trans"])
+@pytest.mark.parametrize("name", ["cornell-box2-transmissive", "dragon-trans", "3-dragon-spec"])
 def test_incoherent_rays_bit_exact(name, gpu_scene, oracle_scenes):
     g = gpu_scene(name)
     orc = oracle_scenes(name)
@@ -98,7 +98,7 @@ def test_incoherent_rays_bit_exact(name, gpu_scene, oracle_scenes):
     _compare_trace(g, orc, o, d, bitmap=False)
 
 
-@pytest.mark.parametrize("name,depth", [("cornell-box2", 5), ("cornell-box2-specular", 8),
+@pytest.mark.parametrize("name,depth", [("3-dragon-spec", 8), ("cornell-box2", 5), ("cornell-box2-specular", 8),
                                          ("cornell-box2-transmissive", 8), ("teapot-trans", 8), ("dragon-trans", 5)])
 def test_path_radiance_matches_oracle(name, depth, gpu_scene, oracle_scenes):
     g = gpu_scene(name)
@@ -274,7 +274,7 @@ def _tie_prone_rays(orc, rng, n):
     return o, d
 
 
-@pytest.mark.parametrize("name", ["cornell-box2-transmissive", "dragon-trans", "teapot"])
+@pytest.mark.parametrize("name", ["cornell-box2-transmissive", "dragon-trans", "teapot", "3-dragon-spec"])
 def test_pipeline_extend_kernel_on_explicit_rays_bit_exact(name, gpu_scene, oracle_scenes):
     """The kernel the renderer launches per bounce (both variants), fed with incoherent and tie-prone
     rays; hit ids and distances are the oracle's bit for bit, its work counters are the oracle's, and

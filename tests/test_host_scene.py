@@ -8,7 +8,7 @@ import pytest
 from conftest import scene_path
 
 ALL = ["cornell-box", "cornell-box2", "cornell-box2-specular", "cornell-box2-transmissive", "teapot", "teapot-trans",
-       "dragon-spec", "dragon-trans"]
+       "dragon-spec", "dragon-trans", "3-dragon-spec"]
 
 
 @pytest.mark.parametrize("name", ALL)
