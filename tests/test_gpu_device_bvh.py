@@ -354,3 +354,70 @@ def test_refit_keeps_the_tree_and_redoes_its_boxes(gpu, oracle, tmp_path):
             fresh.refit(hs_b)  # nothing to refit
     finally:
         fresh.close()
+
+
+def test_binary32_inner_nodes_keep_the_hits_on_hostile_geometry(gpu, oracle, tmp_path):
+    """Extend variants 3 and 4 test inner nodes in binary32 with error margins; their claim is that the hits are those of
+    the exact walk whatever the geometry.  Scenes chosen against the margins: a triangle soup a few million units from
+    the origin whose sizes span six orders of magnitude (the planes lose up to a quarter of a unit to binary32), and a
+    stack of axis-aligned sheets (flat boxes, many coplanar) with rays that start on the sheets' planes, run inside
+    them, have direction components of 1e-12, 1e-200 and exactly 0, or start 1e12 away.  Hit triangle and t bits must
+    equal the oracle's and variant 1's; on the host-built (reference) tree and on the device-built one."""
+    from cuda_path_tracer_amd import HostScene
+    rng = np.random.default_rng(17)
+    centre = np.array([3.0e6, -2.0e6, 4.0e5])
+    soup = []
+    for k in range(2500):
+        size = 10.0 ** rng.uniform(-3, 3)
+        c = centre + rng.normal(size=3) * 2000.0
+        soup.append([c + rng.normal(size=3) * size for _ in range(3)])
+    sheets = []
+    for layer in range(12):
+        z = 0.25 * layer
+        for i in range(6):
+            for j in range(6):
+                x0, y0 = float(i), float(j)
+                sheets.append([np.array([x0, y0, z]), np.array([x0 + 1, y0, z]), np.array([x0, y0 + 1, z])])
+                sheets.append([np.array([x0 + 1, y0 + 1, z]), np.array([x0, y0 + 1, z]), np.array([x0 + 1, y0, z])])
+    for label, tri_points in (("soup", soup), ("sheets", sheets)):
+        text = _mesh_text(tri_points)
+        path = tmp_path / (label + ".ray")
+        path.write_text(text)
+        hs = HostScene(text=text)
+        orc = oracle.OracleScene(str(path))
+        boxes, _ = orc.nodes()
+        lo, hi = boxes[0, :3], boxes[0, 3:]
+        o1, d1 = random_rays(boxes, rng, 6000)
+        o2, d2 = corner_rays(boxes, rng, 6000)
+        # rays that start on box planes and run along them, with tiny and zero direction components
+        n = 3000
+        o3 = rng.uniform(lo, hi, (n, 3))
+        pick = boxes[rng.integers(0, len(boxes), n)]
+        ax = rng.integers(0, 3, n)
+        o3[np.arange(n), ax] = pick[np.arange(n), ax]
+        d3 = rng.normal(size=(n, 3))
+        tiny = np.array([0.0, 1e-12, -1e-12, 1e-200, -1e-200, 1e-300])
+        d3[np.arange(n), ax] = tiny[rng.integers(0, len(tiny), n)]
+        d3[: n // 2] /= np.linalg.norm(d3[: n // 2], axis=1, keepdims=True)
+        # rays from very far away, aimed at the scene
+        o4 = (lo + hi) / 2 + rng.normal(size=(500, 3)) * 1e12
+        d4 = (rng.uniform(lo, hi, (500, 3)) - o4)
+        d4 /= np.linalg.norm(d4, axis=1, keepdims=True)
+        o = np.vstack([o1, o2, o3, o4])
+        d = np.vstack([d1, d2, d3, d4])
+        want = orc.trace(o, d)
+        assert (want["prim"] >= 0).sum() > 200, label
+        for build in ("host", "device"):
+            (gpu.upload if build == "host" else gpu.build)(hs)
+            try:
+                hits = {}
+                for variant in (1, 3, 4):
+                    gpu.set_option("extend_variant", variant)
+                    hits[variant] = gpu.extend_rays(o, d)
+            finally:
+                gpu.set_option("extend_variant", 1)
+            if build == "host":  # the reference's tree: the oracle's hits
+                assert np.array_equal(hits[1][0], want["prim"]) and np.array_equal(bits(hits[1][1]), bits(want["t"])), label
+            for variant in (3, 4):
+                assert np.array_equal(hits[variant][0], hits[1][0]), (label, build, variant)
+                assert np.array_equal(bits(hits[variant][1]), bits(hits[1][1])), (label, build, variant)
