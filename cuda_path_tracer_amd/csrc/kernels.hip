@@ -56,7 +56,9 @@ __device__ __forceinline__ void store_hit(const HitBuf& H, uint32_t p, double t,
     cpt_v2d v;
     v.x = t;
     v.y = __hiloint2double(0, tri);
-    CPT_NT_STORE(((cpt_v2d*)H.rec)[p], v);
+    // an ordinary store, unlike the ray streams' non-temporal ones: the lanes of a wave retire at different times, and
+    // the four 16-byte records of a line are put together in L2 instead of reaching HBM as partial lines
+    ((cpt_v2d*)H.rec)[p] = v;
 }
 __device__ __forceinline__ void load_hit(const HitBuf& H, uint32_t p, double& t, int& tri) {
     const cpt_v2d v = CPT_NT_LOAD(((const cpt_v2d*)H.rec)[p]);
