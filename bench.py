@@ -367,7 +367,7 @@ def main():
     ap.add_argument("--mode", default="wavefront", choices=["wavefront", "mega"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-modes", action="store_true", help="skip the extra measurements of extend variants 3 and 4")
-    ap.add_argument("--batch-paths", type=int, default=1 << 27,
+    ap.add_argument("--batch-paths", type=int, default=1 << 28,
                     help="path slots per batch; the library's own default (2^25) suits short-lived processes, a long-lived one "
                          "can afford the larger allocation and gets shorter launch tails (0: library default)")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight at once (library default when 0)")
