@@ -259,13 +259,12 @@ static int scene_resident(const cpt_ctx* c) {
     return slots <= CPT_PW_CACHE_RECORDS_HOST;
 }
 
-// Rays a wave claims at a time.  A claim stalls the wave for an atomic's round trip, so cheap rays (a
-// scene that sits in the LDS record cache whole) want large chunks; a chunk is also what a wave may be
-// left holding when every other wave has run dry, so expensive rays want smaller ones.
-// Measured on the dragon: 8 M-ray launches 64 beats 256 by 30 %, 64 M-ray launches 128 beats 64 by 2 %.
+// Rays a wave claims at a time.  A claim stalls the wave for an atomic's round trip; a chunk is also what a wave may be
+// left holding when every other wave has run dry, so the kernel itself shortens it for short streams (at least eight
+// claims per wave).  Measured with launches of 2^25 .. 2^28 rays: 256 is as good as or better than 128 on every bundled
+// scene (teapot +1.7 % at 2^28), 64 loses 3-13 %, 512 is the same as 256.
 static int chunk_for(const cpt_ctx* c) {
-    if (c->pw_chunk > 0) return c->pw_chunk;
-    return scene_resident(c) ? 256 : 128;
+    return c->pw_chunk > 0 ? c->pw_chunk : 256;
 }
 
 // Structural validation of the flattened scene: every kernel indexes these arrays without bounds
