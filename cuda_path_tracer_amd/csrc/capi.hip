@@ -394,7 +394,7 @@ static int upload_shading(cpt_ctx* c, const cpt_scene_desc* s) {
         r.index = m.index;
         for (int k = 0; k < 3; ++k) {
             r.ke[k] = m.ke[k]; r.diff_w[k] = m.kd[k]; r.ks[k] = m.ks[k]; r.kr[k] = m.kr[k]; r.kt[k] = m.kt[k];  // diff_w: kd for now
-            r.log_kt[k] = std::log(m.kt[k]);  // -inf for kt = 0, NaN for kt < 0: the kernel then falls back to pow
+            r.log_kt[k] = std::log(std::fabs(m.kt[k]));  // -inf for kt = 0 (kt^t = exp(-inf) = 0); the kernel sees to the sign of a negative kt
         }
     }
     void *d_mat = nullptr, *d_normals = nullptr;

@@ -29,7 +29,7 @@ struct __attribute__((aligned(128))) ShadeRec {
     double r0;                         // ((1 - index) / (1 + index))^2, the same from either side
     double pad1[2];
     double a[3], b[3], c[3];           // third line: vertices, smooth-shaded triangles only
-    double log_kt[3];                  // log(kt), so that kt^t is one exp() at a hit inside the medium
+    double log_kt[3];                  // log|kt|, so that kt^t is one exp() at a hit inside the medium
     double pad2[4];
     double na[3], nb[3], nc[3];        // fourth line: vertex normals
     double pad3[7];

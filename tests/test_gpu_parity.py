@@ -115,6 +115,32 @@ def test_path_radiance_matches_oracle(name, depth, gpu_scene, oracle_scenes):
     assert np.abs(b).sum() > 0
 
 
+@pytest.mark.parametrize("kt", ["(0.0,0.9,0.9)", "(-0.5,0.9,0.0)"])
+def test_transmission_through_a_medium_with_zero_or_negative_kt(kt, gpu, oracle, tmp_path):
+    """kt^t inside a medium (reference: glm::pow at src/path_tracer.cu:326) is computed without pow: a zero kt must
+    still give 0, a negative one pow's NaN (t is never an integer here), channel by channel, as the oracle's pow does."""
+    from cuda_path_tracer_amd import HostScene
+    text = open(scene_path("cornell-box2-transmissive")).read()
+    assert "transmissive=(0.9,0.9,0.9)" in text
+    path = tmp_path / "odd-kt.ray"
+    path.write_text(text.replace("transmissive=(0.9,0.9,0.9)", "transmissive=" + kt))
+    gpu.upload(HostScene(str(path)))
+    orc = oracle.OracleScene(str(path))
+    w = h = 48
+    rng = np.random.default_rng(5)
+    n = 6000
+    ijs = np.stack([rng.integers(0, w, n), rng.integers(0, h, n), rng.integers(0, 64, n)], 1).astype(np.int32)
+    a = gpu.path_radiance(gpu.params(w, h, 0, 64, 8), ijs)
+    b = orc.paths(w, h, 8, ijs)
+    assert (np.isnan(a) == np.isnan(b)).all()
+    close = np.isclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True).all(axis=1)
+    assert (~close).sum() <= 1, "%d of %d paths differ" % ((~close).sum(), n)
+    if "-" in kt:
+        assert np.isnan(b[:, 0]).any() and not np.isnan(b[:, 1]).all()
+    else:
+        assert not np.isnan(b).any() and np.abs(b).sum() > 0
+
+
 @pytest.mark.parametrize("name,depth,dof,rr", [("cornell-box2", 5, 0, 0), ("cornell-box2-transmissive", 6, 0, 0),
                                                 ("teapot-trans", 4, 1, 0), ("cornell-box2-specular", 6, 0, 1)])
 def test_wavefront_render_matches_oracle(name, depth, dof, rr, gpu_scene, oracle_scenes):
