@@ -309,16 +309,22 @@ __device__ __forceinline__ float f32_up(double x) {  // smallest float >= x
     float f = (float)x;
     return ((double)f < x) ? nextafterf(f, INFINITY) : f;
 }
+// A plane beyond the binary32 range is stored as the largest finite float, not as an infinity (0 * inf would put
+// a NaN into the test of an axis the ray does not move on, and minimum/maximum drop NaNs silently).  That is no
+// longer outward for such a plane, and need not be: the scene's extent, taken from the binary64 boxes, is then
+// infinite in binary32, which leaves every axis of every ray unconstrained (see ray32_axis).
+__device__ __forceinline__ float plane_down(double x) { return fmaxf(f32_down(x), -3.4028234663852886e38f); }
+__device__ __forceinline__ float plane_up(double x) { return fminf(f32_up(x), 3.4028234663852886e38f); }
 __global__ void __launch_bounds__(CPT_BLOCK) k_nodes32(const cpt_node* __restrict__ nodes, int n, Node32* __restrict__ out) {
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const cpt_node nd = nodes[k];
         Node32 r;
-        r.lox[0] = f32_down(nd.lbox[0]); r.lox[1] = f32_down(nd.rbox[0]);
-        r.loy[0] = f32_down(nd.lbox[1]); r.loy[1] = f32_down(nd.rbox[1]);
-        r.loz[0] = f32_down(nd.lbox[2]); r.loz[1] = f32_down(nd.rbox[2]);
-        r.hix[0] = f32_up(nd.lbox[3]); r.hix[1] = f32_up(nd.rbox[3]);
-        r.hiy[0] = f32_up(nd.lbox[4]); r.hiy[1] = f32_up(nd.rbox[4]);
-        r.hiz[0] = f32_up(nd.lbox[5]); r.hiz[1] = f32_up(nd.rbox[5]);
+        r.lox[0] = plane_down(nd.lbox[0]); r.lox[1] = plane_down(nd.rbox[0]);
+        r.loy[0] = plane_down(nd.lbox[1]); r.loy[1] = plane_down(nd.rbox[1]);
+        r.loz[0] = plane_down(nd.lbox[2]); r.loz[1] = plane_down(nd.rbox[2]);
+        r.hix[0] = plane_up(nd.lbox[3]); r.hix[1] = plane_up(nd.rbox[3]);
+        r.hiy[0] = plane_up(nd.lbox[4]); r.hiy[1] = plane_up(nd.rbox[4]);
+        r.hiz[0] = plane_up(nd.lbox[5]); r.hiz[1] = plane_up(nd.rbox[5]);
         r.lref = nd.lref; r.rref = nd.rref;
         r.pad_[0] = r.pad_[1] = 0;
         out[k] = r;

@@ -191,7 +191,8 @@ def test_render_on_device_built_tree(name, gpu, host_scenes, oracle):
 
 
 def _mesh_text(tri_points):
-    pts = ",".join("(%r,%r,%r)" % tuple(float(x) for x in p) for tri in tri_points for p in tri)
+    # (the .ray number syntax has no '+': an exponent is written e39, not e+39)
+    pts = ",".join(("(%r,%r,%r)" % tuple(float(x) for x in p)).replace("e+", "e") for tri in tri_points for p in tri)
     faces = ",".join("(%d,%d,%d)" % (3 * k, 3 * k + 1, 3 * k + 2) for k in range(len(tri_points)))
     return ("SBT-raytracer 1.0\ncamera { position = (0.5,0.5,4); viewdir = (0,0,-1); updir = (0,1,0); }\n"
             "polymesh { material = { emissive = (0.5,0.25,1.0); diffuse = (0.5,0.5,0.5); }; points = (%s); faces = (%s); }\n" % (pts, faces))
@@ -421,3 +422,49 @@ def test_binary32_inner_nodes_keep_the_hits_on_hostile_geometry(gpu, oracle, tmp
             for variant in (3, 4):
                 assert np.array_equal(hits[variant][0], hits[1][0]), (label, build, variant)
                 assert np.array_equal(bits(hits[variant][1]), bits(hits[1][1])), (label, build, variant)
+
+
+def test_binary32_inner_nodes_with_planes_beyond_the_binary32_range(gpu, oracle, tmp_path):
+    """Two triangles near 1e39 put box planes beyond the largest float.  The binary32 variants (3 and 4) then cannot
+    constrain any axis and must leave every decision to the exact tests of the leaves: same hits as variant 1 and the
+    oracle, also for rays with zero direction components (where 0 * inf would turn into a NaN that minimum and maximum
+    drop silently)."""
+    from cuda_path_tracer_amd import HostScene
+    rng = np.random.default_rng(23)
+    tris = []
+    for i in range(5):
+        for j in range(5):
+            x0, y0, z = float(i), float(j), 0.1 * ((i + j) % 3)
+            tris.append([np.array([x0, y0, z]), np.array([x0 + 1, y0, z]), np.array([x0, y0 + 1, z])])
+            tris.append([np.array([x0 + 1, y0 + 1, z]), np.array([x0, y0 + 1, z]), np.array([x0 + 1, y0, z])])
+    far = 1.0e39
+    tris.append([np.array([far, far, far]), np.array([far * 1.5, far, far]), np.array([far, far * 1.5, far])])
+    tris.append([np.array([-far, -far, -far]), np.array([-far * 1.5, -far, -far]), np.array([-far, -far * 1.5, -far])])
+    text = _mesh_text(tris)
+    path = tmp_path / "beyond.ray"
+    path.write_text(text)
+    hs = HostScene(text=text)
+    orc = oracle.OracleScene(str(path))
+    n = 4000
+    o = np.column_stack([rng.uniform(-1, 6, n), rng.uniform(-1, 6, n), rng.uniform(1, 3, n)])
+    d = np.column_stack([rng.normal(size=n) * 0.3, rng.normal(size=n) * 0.3, -np.ones(n)])
+    d[:1000, 0] = 0.0
+    d[500:1500, 1] = 0.0
+    d[3000:] *= -1.0  # away from the sheets: misses
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    want = orc.trace(o, d)
+    assert (want["prim"] >= 0).sum() > 1000 and (want["prim"] < 0).sum() > 500
+    for build in ("host", "device"):
+        (gpu.upload if build == "host" else gpu.build)(hs)
+        try:
+            hits = {}
+            for variant in (1, 3, 4):
+                gpu.set_option("extend_variant", variant)
+                hits[variant] = gpu.extend_rays(o, d)
+        finally:
+            gpu.set_option("extend_variant", 1)
+        if build == "host":
+            assert np.array_equal(hits[1][0], want["prim"]) and np.array_equal(bits(hits[1][1]), bits(want["t"]))
+        for variant in (3, 4):
+            assert np.array_equal(hits[variant][0], hits[1][0]), (build, variant)
+            assert np.array_equal(bits(hits[variant][1]), bits(hits[1][1])), (build, variant)
