@@ -256,7 +256,7 @@ static int scene_resident(const cpt_ctx* c) {
     if (!c->has_scene || c->measured_height - 2 > CPT_PW_STACK_LDS_HOST) return 0;
     // 128-byte slots the scene takes in the record cache (binary32 node records are half a slot each)
     const long long slots = variant_f32(c) ? (c->sc.n_nodes + 1) / 2 + (long long)c->sc.n_tris : (long long)c->sc.n_nodes + c->sc.n_tris;
-    return slots <= CPT_PW_CACHE_RECORDS_HOST;
+    return slots <= (variant_f32(c) ? CPT_PW_CACHE_RECORDS_HOST : CPT_PW_PLANAR_SLOTS_HOST);
 }
 
 // Rays a wave claims at a time.  A claim stalls the wave for an atomic's round trip; a chunk is also what a wave may be

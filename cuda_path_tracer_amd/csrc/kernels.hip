@@ -205,8 +205,10 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
 // path, not arithmetic, bounds the kernel.  The workgroup therefore keeps the head of the node
 // array (records are stored top of the tree first) and the head of the triangle array in LDS, 64 KB
 // shared by its 16 waves: small scenes live there entirely, large ones keep their upper levels
-// there.  A cached record's eight 16-byte pieces are stored rotated by an XOR with (r >> 1) & 7 so
-// that lanes reading the same piece of different records spread over the LDS banks.
+// there.  The exact variants keep the cache as seven planes (piece k of every cached record side by side, see
+// fetch_record): consecutive records are 16 bytes apart in a plane, so lanes reading the same piece of different
+// records spread over the LDS banks, and a fetch computes one address.  The binary32 variants keep whole records,
+// their pieces rotated by an XOR (with (r >> 1) & 7 for a 128-byte record) to the same end.
 //
 // Queue entries are claimed in chunks: one atomic per `chunk` rays, the rest is wave-local.
 // The per-lane node stack keeps its first CPT_PW_STACK_LDS entries in LDS; deeper entries (rare)
@@ -237,11 +239,23 @@ __device__ __forceinline__ double2 lds_piece(const lds_byte* p) {
     v2d v = *(const lds_v2d*)p;
     return make_double2(v.x, v.y);
 }
-template <bool RESIDENT>
+// PLANAR: the cache holds piece k of slot s at k * CPT_PW_PLANE_BYTES + s * 16 (seven planes of 16-byte pieces; the
+// eighth piece of a record is never read): one address per fetch, the planes are reached through the instruction's
+// offset field, and lanes reading different slots spread over the banks without any swizzle.
+#define CPT_PW_PLANE_SLOTS CPT_PW_PLANAR_SLOTS_HOST  // 585: seven planes of that many 16-byte pieces are the cache's 64 KB
+#define CPT_PW_PLANE_BYTES (CPT_PW_PLANE_SLOTS * 16)
+static_assert(7 * CPT_PW_PLANE_BYTES <= CPT_PW_CACHE_RECORDS * 128, "the seven planes must fit the cache");
+template <bool RESIDENT, bool PLANAR>
 __device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, const lds_byte* cache, int cache_first,
                                              int cached, int idx) {
     Rec7 r;
-    if (RESIDENT || idx < cached) {
+    if (PLANAR && (RESIDENT || idx < cached)) {
+        const lds_byte* rec = cache + (uint32_t)(cache_first + idx) * 16u;
+        r.p0 = lds_piece(rec); r.p1 = lds_piece(rec + CPT_PW_PLANE_BYTES);
+        r.p2 = lds_piece(rec + 2 * CPT_PW_PLANE_BYTES); r.p3 = lds_piece(rec + 3 * CPT_PW_PLANE_BYTES);
+        r.p4 = lds_piece(rec + 4 * CPT_PW_PLANE_BYTES); r.p5 = lds_piece(rec + 5 * CPT_PW_PLANE_BYTES);
+        r.p6 = lds_piece(rec + 6 * CPT_PW_PLANE_BYTES);
+    } else if (RESIDENT || idx < cached) {
         const uint32_t slot = (uint32_t)(cache_first + idx);
         const lds_byte* rec = cache + slot * 128u;
         const uint32_t z = (slot >> 1) & 7u;
@@ -416,12 +430,13 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     // (F32: 64-byte binary32 node records, twice as many per byte; triangle records start at the next 128-byte slot)
     // A scene that does not fit whole keeps CPT_PW_HOT_TRIS slots for its first triangles, which the library has put
     // largest bounding box first: those few take most of the triangle tests.
-    const bool fits = (F32 ? (sc.n_nodes + 1) / 2 : sc.n_nodes) + sc.n_tris <= CPT_PW_CACHE_RECORDS;
+    constexpr int kSlots = F32 ? CPT_PW_CACHE_RECORDS : CPT_PW_PLANE_SLOTS;  // record slots of this variant's cache layout
+    const bool fits = (F32 ? (sc.n_nodes + 1) / 2 : sc.n_nodes) + sc.n_tris <= kSlots;
     const int tri_reserve = fits ? 0 : (sc.n_tris < CPT_PW_HOT_TRIS ? sc.n_tris : CPT_PW_HOT_TRIS);
-    const int node_room = F32 ? (CPT_PW_CACHE_RECORDS - tri_reserve) * 2 : CPT_PW_CACHE_RECORDS - tri_reserve;
+    const int node_room = F32 ? (kSlots - tri_reserve) * 2 : kSlots - tri_reserve;
     const int cached_nodes = sc.n_nodes < node_room ? sc.n_nodes : node_room;
     const int tri_first = F32 ? (cached_nodes + 1) / 2 : cached_nodes;  // first 128-byte slot of the cached triangles
-    const int room = CPT_PW_CACHE_RECORDS - tri_first;
+    const int room = kSlots - tri_first;
     const int cached_tris = sc.n_tris < room ? sc.n_tris : room;
     if (F32) {
         for (int i = (int)threadIdx.x; i < cached_nodes * 4; i += CPT_PW_THREADS) {
@@ -439,7 +454,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
             int r = i >> 3, c = i & 7;
             const unsigned char* src = r < cached_nodes ? (const unsigned char*)sc.nodes + (size_t)r * 128
                                                         : (const unsigned char*)sc.tris + (size_t)(r - cached_nodes) * 128;
-            *(double2*)(s_cache + (size_t)r * 128 + (((uint32_t)c ^ (((uint32_t)r >> 1) & 7u)) << 4)) = *(const double2*)(src + c * 16);
+            if (c < 7) *(double2*)(s_cache + (size_t)c * CPT_PW_PLANE_BYTES + (size_t)r * 16) = *(const double2*)(src + c * 16);  // planar, see fetch_record
         }
     }
     // the largest plane magnitude of the scene (the root's two child boxes contain everything): scale of the
@@ -545,7 +560,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                     enter_l = (double)el;
                     enter_r = (double)er;
                 } else {
-                    Rec7 r = fetch_record<RESIDENT>(sc.nodes, cache, 0, cached_nodes, node);
+                    Rec7 r = fetch_record<RESIDENT, true>(sc.nodes, cache, 0, cached_nodes, node);
                     refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));
                     bool sure_l, sure_r;
                     hl = slab_filtered(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, sr, sure_l, enter_l);
@@ -599,7 +614,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 if (lp > 0) {
                     --lp;
                     int tri = (int)my_leaves[lp * CPT_WAVE];
-                    Rec7 q = fetch_record<RESIDENT>(sc.tris, cache, tri_first, cached_tris, tri);
+                    Rec7 q = fetch_record<RESIDENT, !F32>(sc.tris, cache, tri_first, cached_tris, tri);
                     uint32_t flags = (uint32_t)__double2hiint(q.p6.x), rank = (uint32_t)__double2loint(q.p6.y);
                     bool gate = true;
                     if (F32 && sc.n_nodes > 0) {  // (a one-triangle scene has no boxes at all) the exact test of the leaf's own box: the bounds of the three vertices (reference: src/scene/bvh.cpp:128-146)

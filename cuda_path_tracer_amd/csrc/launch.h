@@ -132,7 +132,8 @@ struct Radiance {           // radiance gathered per path, indexed by slot; touc
 // Positions a stream of n rays needs, and the capacity of one of its CPT_PW_SEGMENTS segments.
 inline uint32_t cpt_segment_cap(size_t n) { return (uint32_t)(((n + CPT_PW_SEGMENTS - 1) / CPT_PW_SEGMENTS + 63) / 64 * 64); }
 inline size_t cpt_stream_positions(size_t n) { return (size_t)cpt_segment_cap(n) * CPT_PW_SEGMENTS; }
-#define CPT_PW_CACHE_RECORDS_HOST 512  // records of the scene the persistent extend kernel keeps in LDS
+#define CPT_PW_CACHE_RECORDS_HOST 512  // 128-byte records of the scene the persistent extend kernel keeps in LDS (its 64 KB record cache) ...
+#define CPT_PW_PLANAR_SLOTS_HOST 585   // ... and how many the exact variants keep, which store only the seven 16-byte pieces of a record that are ever read
 #define CPT_PW_THREADS_HOST 1024
 
 struct LaunchCfg {
