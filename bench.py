@@ -99,7 +99,7 @@ def host_cpus():
     return total, usable
 
 
-def cpu_baseline(workload, seconds_target=10.0):
+def cpu_baseline(workload, seconds_target=10.0, also=()):
     """The reference's CPU path tracer (oracle restatement: branching estimator, recursive BVH walk, one
     generator per thread), timed on this box's host cores.  Two measurements: BASELINE configs[0] exactly
     (cornell-box2, 512x512, 16 spp, depth 5 -- the size the reference's own CPU timings are quoted on), and a bounded
@@ -113,28 +113,36 @@ def cpu_baseline(workload, seconds_target=10.0):
     _, _, s1 = sc.render_cpu_reference(w, w, cfg1["spp"], cfg1["depth"], threads)
     cfg1_rec = {"workload": cfg1["desc"], "value": w * w * cfg1["spp"] / s1 / 1e6, "unit": "Mpaths/s", "seconds": s1,
                 "paths": w * w * cfg1["spp"], "sample": "the whole configuration, not a sample"}
-    paths = 0
-    secs = 0.0
-    w = 64
-    spp = 1
-    for name in workload["scenes"]:
-        sc = pyoracle.OracleScene(scene_file(name))
-        per_scene = seconds_target / len(workload["scenes"])
-        t_scene = 0.0
-        n_scene = 0
-        while t_scene < per_scene and spp <= 65536:
-            _, _, s = sc.render_cpu_reference(w, w, spp, workload["depth"], threads)
-            t_scene += s
-            n_scene += w * w * spp
-            if s < per_scene / 3:
-                spp *= 2
-        paths += n_scene
-        secs += t_scene
-    return {"value": paths / secs / 1e6, "unit": "Mpaths/s", "cores": cores, "threads": threads, "kind": "port",
-            "sample": "oracle restatement of the reference CPU path tracer (src/path_tracer.cu:27-238 on the thread pool of "
-                      "src/RayTracer.cpp:657-694), 64x64 px of each scene of the headline workload at depth %d, %d paths in "
-                      "%.1f s on %d threads (machine: %d CPUs)" % (workload["depth"], paths, secs, threads, cores),
-            "cfg1": cfg1_rec}
+    def sample(wl, seconds):
+        paths, secs, w, spp = 0, 0.0, 64, 1
+        for name in wl["scenes"]:
+            sc = pyoracle.OracleScene(scene_file(name))
+            per_scene = seconds / len(wl["scenes"])
+            t_scene = 0.0
+            n_scene = 0
+            while t_scene < per_scene and spp <= 65536:
+                _, _, s = sc.render_cpu_reference(w, w, spp, wl["depth"], threads)
+                t_scene += s
+                n_scene += w * w * spp
+                if s < per_scene / 3:
+                    spp *= 2
+            paths += n_scene
+            secs += t_scene
+        return paths, secs
+
+    paths, secs = sample(workload, seconds_target)
+    rec = {"value": paths / secs / 1e6, "unit": "Mpaths/s", "cores": cores, "threads": threads, "kind": "port",
+           "sample": "oracle restatement of the reference CPU path tracer (src/path_tracer.cu:27-238 on the thread pool of "
+                     "src/RayTracer.cpp:657-694), 64x64 px of each scene of the headline workload at depth %d, %d paths in "
+                     "%.1f s on %d threads (machine: %d CPUs)" % (workload["depth"], paths, secs, threads, cores),
+           "cfg1": cfg1_rec}
+    for name in also:  # the other workloads of the line, a shorter sample each
+        p2, s2 = sample(WORKLOADS[name], seconds_target / 2)
+        rec[name] = {"value": p2 / s2 / 1e6, "unit": "Mpaths/s",
+                     "sample": "64x64 px of %s at depth %d, %d paths in %.1f s on %d threads; per-path cost does not depend on the image "
+                               "size or the sample count, so the rate carries over to the full configuration" %
+                               (" + ".join(WORKLOADS[name]["scenes"]), WORKLOADS[name]["depth"], p2, s2, threads)}
+    return rec
 
 
 def self_launch(args):
@@ -421,7 +429,7 @@ def main():
                           "rccl_ranks": b.ranks_seen, "backend": b.backend if b.distributed else None},
                "roofline": head["roofline"], "workloads": extras, "fast_modes": fast}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl)
+            out["cpu_baseline"] = cpu_baseline(wl, also=[n for n in names if n == "dragon"])
         print(json.dumps(out), flush=True)
     if b.distributed:
         b.dist.barrier()
