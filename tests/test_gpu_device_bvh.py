@@ -468,3 +468,29 @@ def test_binary32_inner_nodes_with_planes_beyond_the_binary32_range(gpu, oracle,
         for variant in (3, 4):
             assert np.array_equal(hits[variant][0], hits[1][0]), (build, variant)
             assert np.array_equal(bits(hits[variant][1]), bits(hits[1][1])), (build, variant)
+
+
+def test_scene_sizes_around_the_record_cache_capacity(gpu):
+    """The persistent extend kernel keeps 585 records in LDS in the exact variants (512 slots in the binary32 ones, a
+    node record taking half a slot there) and runs another template instance when the whole scene fits.  Triangle
+    counts on both sides of every such boundary (a device-built tree over n triangles has n - 1 nodes: 2n - 1 <= 585
+    up to n = 293, 1.5n <= 512 up to n = 341) must give the hits of the one-ray-per-thread kernel, bit for bit."""
+    from cuda_path_tracer_amd import HostScene
+    rng = np.random.default_rng(41)
+    for n in (255, 256, 257, 292, 293, 294, 340, 341, 342, 343, 600):
+        tris = [_small_tri(rng.uniform(-1, 1, 3), 10.0 ** rng.uniform(-2, -0.5), rng) for _ in range(n)]
+        gpu.build(HostScene(text=_mesh_text(tris)))
+        o = rng.uniform(-1.3, 1.3, (6000, 3))
+        d = rng.normal(size=(6000, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        try:
+            hits = {}
+            for variant in (0, 1, 2, 3, 4):
+                gpu.set_option("extend_variant", variant)
+                hits[variant] = gpu.extend_rays(o, d)
+        finally:
+            gpu.set_option("extend_variant", 1)
+        assert (hits[0][0] >= 0).sum() > 300, n
+        for variant in (1, 2, 3, 4):
+            assert np.array_equal(hits[variant][0], hits[0][0]), (n, variant)
+            assert np.array_equal(bits(hits[variant][1]), bits(hits[0][1])), (n, variant)
