@@ -235,6 +235,7 @@ struct Rec7 {  // the first seven 16-byte pieces of a 128-byte record
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) v2d lds_v2d;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ double2 lds_piece(const lds_byte* p) {
     v2d v = *(const lds_v2d*)p;
     return make_double2(v.x, v.y);
@@ -470,7 +471,14 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     const lds_byte* cache = (const lds_byte*)s_cache;
 
     uint32_t* my_nodes = &s_nodes[wave][0][lane];    // entry e at my_nodes[e * CPT_WAVE]
-    uint32_t* my_leaves = &s_leaves[wave][0][lane];
+    // The parked-leaf list is addressed by a pointer to its next free entry, not by a count: a push is one LDS write
+    // and one add.  Entries hold the child reference as the node record has it (~triangle index).
+    lds_u32* const leaf_base = (lds_u32*)&s_leaves[wave][0][lane];  // entries are CPT_WAVE words apart
+    lds_u32* leaf_top = leaf_base;
+#define CPT_LEAVES_AT_MOST(N) (leaf_top <= leaf_base + (N) * CPT_WAVE)
+    // likewise the node stack of the RESIDENT instances (the others count entries: theirs continues in global memory)
+    lds_u32* const node_base = (lds_u32*)&s_nodes[wave][0][lane];
+    lds_u32* node_top = node_base;
     uint32_t* my_spill = spill + (size_t)blockIdx.x * CPT_PW_THREADS + threadIdx.x;  // entry e at my_spill[e * spill_stride]
     const size_t spill_stride = (size_t)gridDim.x * CPT_PW_THREADS;
     uint32_t chunk_pos = 0, chunk_end = 0;  // wave-uniform: unclaimed part of this wave's chunk
@@ -478,7 +486,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     uint32_t seg = (blockIdx.x * CPT_PW_WAVES + wave) % CPT_PW_SEGMENTS, segs_empty = 0;  // wave-uniform: segment being claimed from
 
     bool has_ray = false;
-    int node = -1, sp = 0, lp = 0;
+    int node = -1, sp = 0;
     uint32_t pos = 0;  // stream position of this lane's ray
     dvec3 o = dv(0, 0, 0), d = dv(0, 0, 1);
     SlabRay sr = slab_prepare(o, dv(1, 1, 1));
@@ -519,14 +527,15 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 best_tri = -1;
                 best_rank = 0xFFFFFFFFu;
                 sp = 0;
-                lp = 0;
+                node_top = node_base;
+                leaf_top = leaf_base;
                 has_ray = true;
                 if (sc.n_nodes > 0) {
                     node = 0;
                 } else {  // one-triangle scene
                     node = -1;
-                    my_leaves[0] = 0u;
-                    lp = 1;
+                    *leaf_base = ~0u;  // ~(triangle 0)
+                    leaf_top = leaf_base + CPT_WAVE;
                 }
             }
             chunk_pos += take;
@@ -543,10 +552,10 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
 #pragma unroll
         for (int rep = 0; rep < CPT_PW_BOX_REPEAT; ++rep) {
             if (COUNT) {
-                uint64_t boxing = __ballot(node >= 0 && lp <= CPT_PW_LEAF_CAP - 2);
+                uint64_t boxing = __ballot(node >= 0 && CPT_LEAVES_AT_MOST(CPT_PW_LEAF_CAP - 2));
                 if (lane == 0 && boxing) box_passes++;
             }
-            if (node >= 0 && lp <= CPT_PW_LEAF_CAP - 2) {
+            if (node >= 0 && CPT_LEAVES_AT_MOST(CPT_PW_LEAF_CAP - 2)) {
                 int2 refs;  // lref, rref
                 bool hl, hr;
                 double enter_l, enter_r;
@@ -582,13 +591,25 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                     }
                 }
                 if (COUNT) steps++;
-                if (hl && refs.x < 0) { my_leaves[lp * CPT_WAVE] = (uint32_t)(~refs.x); ++lp; }
-                if (hr && refs.y < 0) { my_leaves[lp * CPT_WAVE] = (uint32_t)(~refs.y); ++lp; }
+                if (hl && refs.x < 0) { *leaf_top = (uint32_t)refs.x; leaf_top += CPT_WAVE; }
+                if (hr && refs.y < 0) { *leaf_top = (uint32_t)refs.y; leaf_top += CPT_WAVE; }
                 bool tl = hl && refs.x >= 0, tr = hr && refs.y >= 0;
-                if (tl) {
+                if (RESIDENT) {
+                    if (tl) {
+                        node = refs.x;
+                        if (tr) { *node_top = (uint32_t)refs.y; node_top += CPT_WAVE; }
+                    } else if (tr) {
+                        node = refs.y;
+                    } else if (node_top != node_base) {
+                        node_top -= CPT_WAVE;
+                        node = (int)*node_top;
+                    } else {
+                        node = -1;
+                    }
+                } else if (tl) {
                     node = refs.x;
                     if (tr) {
-                        if (RESIDENT || sp < CPT_PW_STACK_LDS) my_nodes[sp * CPT_WAVE] = (uint32_t)refs.y;
+                        if (sp < CPT_PW_STACK_LDS) my_nodes[sp * CPT_WAVE] = (uint32_t)refs.y;
                         else my_spill[(size_t)(sp - CPT_PW_STACK_LDS) * spill_stride] = (uint32_t)refs.y;
                         ++sp;
                     }
@@ -596,7 +617,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                     node = refs.y;
                 } else if (sp > 0) {
                     --sp;
-                    if (RESIDENT || sp < CPT_PW_STACK_LDS) node = (int)my_nodes[sp * CPT_WAVE];
+                    if (sp < CPT_PW_STACK_LDS) node = (int)my_nodes[sp * CPT_WAVE];
                     else node = (int)my_spill[(size_t)(sp - CPT_PW_STACK_LDS) * spill_stride];
                 } else {
                     node = -1;
@@ -605,15 +626,15 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
         }
 
         // ---- triangle phase: when enough lanes have a parked leaf, or nothing else can run ----
-        uint64_t have_leaf = __ballot(lp > 0);
+        uint64_t have_leaf = __ballot(leaf_top != leaf_base);
         if (have_leaf) {
             uint64_t have_node = __ballot(node >= 0);
-            uint64_t nearly_full = __ballot(lp > CPT_PW_LEAF_CAP - 2);
+            uint64_t nearly_full = __ballot(!CPT_LEAVES_AT_MOST(CPT_PW_LEAF_CAP - 2));
             if ((uint32_t)__popcll(have_leaf) >= leaf_go || (have_node & ~nearly_full) == 0 || (uint32_t)__popcll(nearly_full) >= full_go) {
                 if (COUNT && lane == 0) leaf_passes++;
-                if (lp > 0) {
-                    --lp;
-                    int tri = (int)my_leaves[lp * CPT_WAVE];
+                if (leaf_top != leaf_base) {
+                    leaf_top -= CPT_WAVE;
+                    int tri = (int)~*leaf_top;
                     Rec7 q = fetch_record<RESIDENT, !F32>(sc.tris, cache, tri_first, cached_tris, tri);
                     uint32_t flags = (uint32_t)__double2hiint(q.p6.x), rank = (uint32_t)__double2loint(q.p6.y);
                     bool gate = true;
@@ -642,7 +663,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
         }
 
         // ---- retire ----
-        if (has_ray && node < 0 && lp == 0) {
+        if (has_ray && node < 0 && leaf_top == leaf_base) {
             store_hit(hit, pos, best_t, best_tri);
             has_ray = false;
         }
