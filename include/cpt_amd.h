@@ -152,7 +152,7 @@ int cpt_set_stream(cpt_ctx* ctx, void* hip_stream);
  * but a short-lived process that allocates tens of GB makes the next one wait for the driver to reclaim them; launches of tens of millions of rays
  * keep the persistent kernel's tail short), "streams" (batches in flight at once, each on its own HIP stream, so that one
  * batch's intersection kernel overlaps another's shading kernel; default 2, at most 4; the result
- * does not depend on it), "max_blocks" (grid cap of the grid-stride kernels, default 8 per CU),
+ * does not depend on it), "max_blocks" (grid cap of the grid-stride kernels, default 8 per CU; the shade kernel takes five times that),
  * "extend_variant" (1: persistent waves with an LDS record cache, default; 0: one ray per thread;
  * 2: as 1 but walking the nearer child first and skipping boxes entered beyond the closest hit so
  * far -- a fast mode that returns the same hits without reproducing the reference's visit set;
