@@ -81,7 +81,7 @@ MODE_MEGAKERNEL = 1
 AMD_SYMBOLS = [
     "cpt_create", "cpt_destroy", "cpt_last_error", "cpt_set_stream", "cpt_set_option", "cpt_set_instrumentation",
     "cpt_upload_scene", "cpt_build_scene", "cpt_refit_scene", "cpt_download_tree", "cpt_render", "cpt_render_noalloc", "cpt_tonemap", "cpt_render_image", "cpt_render_progressive", "cpt_synchronize", "cpt_get_stats",
-    "cpt_reset_stats", "cpt_extend_rays", "cpt_trace_rays", "cpt_camera_rays", "cpt_path_radiance", "cpt_probe_math", "cpt_probe_rng",
+    "cpt_reset_stats", "cpt_extend_rays", "cpt_extend_rays_observed", "cpt_trace_rays", "cpt_camera_rays", "cpt_path_radiance", "cpt_probe_math", "cpt_probe_rng",
 ]
 # every symbol include/cpt_host.h declares
 HOST_SYMBOLS = [
@@ -120,6 +120,11 @@ def amd():
         L.cpt_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.cpt_reset_stats.argtypes = [vp]
         L.cpt_extend_rays.argtypes = [vp, i32, vp, vp, vp, vp]
+        try:
+            L.cpt_extend_rays_observed.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32]
+        except AttributeError:  # only an older A/B build named by CPT_AMD_LIBRARY may lack an entry point
+            if not os.environ.get("CPT_AMD_LIBRARY"):
+                raise
         L.cpt_trace_rays.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32]
         L.cpt_camera_rays.argtypes = [vp, i32, i32, dbl, dbl, vp, vp]
         L.cpt_path_radiance.argtypes = [vp, C.POINTER(RenderParams), i32, vp, vp]

@@ -651,7 +651,7 @@ static int ensure_spill(cpt_ctx* c, cpt_ctx::Lane& l, hipStream_t st) {
     HIP_TRY(c, hipStreamSynchronize(st));
     if (l.d_spill) (void)hipFree(l.d_spill);
     l.d_spill = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&l.d_spill, (size_t)(CPT_PW_STACK_MAX - CPT_PW_STACK_LDS_HOST) * (size_t)c->pw_blocks * CPT_PW_THREADS_HOST * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&l.d_spill, (size_t)(CPT_PW_STACK_MAX - CPT_PW_STACK_LDS_LARGE_HOST) * (size_t)c->pw_blocks * CPT_PW_THREADS_HOST * sizeof(uint32_t)));
     l.spill_blocks = c->pw_blocks;
     return CPT_OK;
 }
@@ -755,8 +755,8 @@ static int run_wavefront(cpt_ctx* c, const DParams& P, LaunchCfg L, cpt_ctx::Lan
         for (int b = 0; b <= P.depth; ++b) {
             const RayStream& in = ln.R[b & 1];
             uint32_t* count_in = ln.d_counters + (size_t)b * CPT_PW_CURSOR_WORDS;
-            if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, count_in, cap, cursors + (size_t)b * CPT_PW_CURSOR_WORDS, ln.d_spill, work);
-            else launch_extend(L, c->sc, in, ln.H, count_in, cap, slots, work);
+            if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, count_in, cap, cursors + (size_t)b * CPT_PW_CURSOR_WORDS, ln.d_spill, work, ExtendObserve{nullptr, nullptr, 0});
+            else launch_extend(L, c->sc, in, ln.H, count_in, cap, slots, work, ExtendObserve{nullptr, nullptr, 0});
             if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
             launch_shade(L, c->sc, P, in, ln.H, ln.R[(b + 1) & 1], ln.C, bs, b, count_in, count_in + CPT_PW_CURSOR_WORDS, cap, slots, work);
             if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
@@ -859,7 +859,7 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
 // the LDS part, for every thread of every persistent workgroup.
 static size_t spill_bytes_needed(const cpt_ctx* c) {
     if (c->extend_variant < 1) return 0;
-    const int entries = std::max(c->measured_height, c->tree_height) - 2 - CPT_PW_STACK_LDS_HOST;
+    const int entries = std::max(c->measured_height, c->tree_height) - 2 - CPT_PW_STACK_LDS_LARGE_HOST;
     return entries > 0 ? (size_t)entries * (size_t)c->pw_blocks * CPT_PW_THREADS_HOST * sizeof(uint32_t) : 0;
 }
 
@@ -1051,9 +1051,15 @@ int cpt_trace_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, 
     return CPT_OK;
 }
 
-int cpt_extend_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, int32_t* h_tri, double* h_t) {
-    if (!c || !h_o || !h_d || !h_tri || !h_t || n < 0) return c ? fail(c, CPT_EINVAL, "cpt_extend_rays: bad argument") : CPT_EINVAL;
-    if (!c->has_scene) return fail(c, CPT_ENOSCENE, "cpt_extend_rays: no scene uploaded");
+// cpt_extend_rays and cpt_extend_rays_observed: the rays go into lane 0's first stream as a dense run and through
+// one launch of the extend kernel the renderer would use; with `observe` it is the kernel's counting instance, which
+// also reports what each ray's walk touched.
+static int extend_rays_impl(cpt_ctx* c, const char* who, int32_t n, const double* h_o, const double* h_d, int32_t* h_tri, double* h_t,
+                            bool observe, uint64_t* h_vhash, uint8_t* h_bitmap, int32_t stride) {
+    if (!c || !h_o || !h_d || !h_tri || !h_t || n < 0) return c ? fail(c, CPT_EINVAL, "%s: bad argument", who) : CPT_EINVAL;
+    if (!c->has_scene) return fail(c, CPT_ENOSCENE, "%s: no scene uploaded", who);
+    if (h_bitmap && (stride < 1 || (long long)stride * 8 < c->n_tree_nodes))
+        return fail(c, CPT_EINVAL, "%s: bitmap_stride %d too small for %d nodes", who, stride, c->n_tree_nodes);
     if (n == 0) return CPT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     cpt_ctx::Lane& ln = c->lanes[0];
@@ -1062,6 +1068,15 @@ int cpt_extend_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d,
     rc = ensure_paths(c, ln, c->stream, cpt_stream_positions((size_t)n));
     if (rc) return rc;
     const size_t N = (size_t)n;
+    DevBuf vh, bm;
+    ExtendObserve obs{nullptr, nullptr, 0};
+    if (observe && h_vhash) { HIP_TRY(c, vh.alloc(N * 8)); HIP_TRY(c, hipMemsetAsync(vh.p, 0, N * 8, c->stream)); obs.vhash = (unsigned long long*)vh.p; }
+    if (observe && h_bitmap) {
+        HIP_TRY(c, bm.alloc(N * (size_t)stride));
+        HIP_TRY(c, hipMemsetAsync(bm.p, 0, N * (size_t)stride, c->stream));
+        obs.bitmap = (uint8_t*)bm.p;
+        obs.bitmap_stride = stride;
+    }
     std::vector<double> packed(6 * N);  // the stream keeps components in pairs: (ox, oy) | (oz, dx) | (dy, dz)
     for (size_t i = 0; i < N; ++i) {
         const double v[6] = {h_o[3 * i], h_o[3 * i + 1], h_o[3 * i + 2], h_d[3 * i], h_d[3 * i + 1], h_d[3 * i + 2]};
@@ -1074,21 +1089,33 @@ int cpt_extend_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d,
     HIP_TRY(c, hipMemsetAsync(cursors, 0, CPT_PW_CURSOR_WORDS * sizeof(uint32_t), c->stream));
     const uint32_t cap = cpt_segment_cap((size_t)n);
     LaunchCfg L = launch_cfg(c);
-    unsigned long long* work = c->count_work ? c->d_work : nullptr;
+    unsigned long long* work = (c->count_work || observe) ? c->d_work : nullptr;
     launch_dense_counts(L, ln.d_counters, (uint32_t)n, cap);
-    if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, ln.d_counters, cap, cursors, ln.d_spill, work);
-    else launch_extend(L, c->sc, in, ln.H, ln.d_counters, cap, (long long)n, work);
+    if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, ln.d_counters, cap, cursors, ln.d_spill, work, obs);
+    else launch_extend(L, c->sc, in, ln.H, ln.d_counters, cap, (long long)n, work, obs);
     HIP_TRY(c, hipGetLastError());
     c->stats.launches_extend++;
     std::vector<HitRec> recs(N);
     HIP_TRY(c, hipMemcpyAsync(recs.data(), ln.H.rec, N * sizeof(HitRec), hipMemcpyDeviceToHost, c->stream));
+    if (obs.vhash) HIP_TRY(c, hipMemcpyAsync(h_vhash, vh.p, N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (obs.bitmap) HIP_TRY(c, hipMemcpyAsync(h_bitmap, bm.p, N * (size_t)stride, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < N; ++i) {
         h_t[i] = recs[i].t;
         h_tri[i] = (recs[i].tri >= 0 && !c->tri_ext.empty()) ? c->tri_ext[(size_t)recs[i].tri] : recs[i].tri;
     }
-    if (work) return collect_work(c);
+    if (c->count_work) return collect_work(c);
+    if (work) HIP_TRY(c, hipMemsetAsync(c->d_work, 0, 8 * sizeof(unsigned long long), c->stream));  // counted only because the instance does
     return CPT_OK;
+}
+
+int cpt_extend_rays(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, int32_t* h_tri, double* h_t) {
+    return extend_rays_impl(c, "cpt_extend_rays", n, h_o, h_d, h_tri, h_t, false, nullptr, nullptr, 0);
+}
+
+int cpt_extend_rays_observed(cpt_ctx* c, int32_t n, const double* h_o, const double* h_d, int32_t* h_tri, double* h_t,
+                             uint64_t* h_vhash, uint8_t* h_bitmap, int32_t stride) {
+    return extend_rays_impl(c, "cpt_extend_rays_observed", n, h_o, h_d, h_tri, h_t, true, h_vhash, h_bitmap, stride);
 }
 
 int cpt_camera_rays(cpt_ctx* c, int32_t w, int32_t h, double jx, double jy, double* h_o, double* h_d) {

@@ -162,7 +162,8 @@ __global__ void k_dense_counts(uint32_t* __restrict__ counts, uint32_t n, uint32
 // reference: the intersection half of pathTrace (src/improved_path_tracer.cu:56-76)
 template <bool COUNT>
 __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, HitBuf hit,
-                                                      const uint32_t* __restrict__ counter, uint32_t cap, unsigned long long* work) {
+                                                      const uint32_t* __restrict__ counter, uint32_t cap, unsigned long long* work,
+                                                      ExtendObserve obs) {
     CPT_DECLARE_STACK
     __shared__ uint32_t s_count[CPT_PW_SEGMENTS];
     if (threadIdx.x < CPT_PW_SEGMENTS) s_count[threadIdx.x] = counter[threadIdx.x * 32u];
@@ -178,10 +179,11 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
         double t;
         int tri;
         if (COUNT) {
-            TraceRec rec = {0, 0, 0, 0, 0, nullptr};
+            TraceRec rec = {0, 0, 0, 0, 0, obs.bitmap ? obs.bitmap + (size_t)q * (size_t)obs.bitmap_stride : nullptr};
             traverse<true>(sc, o, d, my_stack, t, tri, &rec);
             steps += (unsigned long long)rec.node_steps;
             tris += (unsigned long long)rec.tri_tests;
+            if (obs.vhash) obs.vhash[q] = rec.visit_hash;
         } else {
             traverse<false>(sc, o, d, my_stack, t, tri, nullptr);
         }
@@ -211,23 +213,56 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
 // their pieces rotated by an XOR (with (r >> 1) & 7 for a 128-byte record) to the same end.
 //
 // Queue entries are claimed in chunks: one atomic per `chunk` rays, the rest is wave-local.
-// The per-lane node stack keeps its first CPT_PW_STACK_LDS entries in LDS; deeper entries (rare)
+// The per-lane node stack keeps its first entries in LDS (PwPlan::STACK_LDS); deeper entries (rare)
 // go to a per-lane column of `spill` in global memory.
 #ifndef CPT_PW_THREADS
 #define CPT_PW_THREADS 1024
 #endif
 #define CPT_PW_WAVES (CPT_PW_THREADS / CPT_WAVE)
 #define CPT_PW_CACHE_RECORDS 512  // 64 KB of 128-byte records
-#define CPT_PW_STACK_LDS 12
 static_assert(CPT_PW_CACHE_RECORDS == CPT_PW_CACHE_RECORDS_HOST, "record cache size must match the host's chunk choice");
-static_assert(CPT_PW_STACK_LDS == CPT_PW_STACK_LDS_HOST, "stack split must match the spill buffer sizing");
 #ifndef CPT_PW_BOX_REPEAT
 #define CPT_PW_BOX_REPEAT 3   // node expansions per lane and loop turn
 #endif
-#define CPT_PW_LEAF_CAP 10    // parked leaves per lane (a node expansion adds at most two)
 #ifndef CPT_PW_HOT_TRIS
 #define CPT_PW_HOT_TRIS 32    // record-cache slots kept for triangles when the node records alone would fill it
 #endif
+#ifndef CPT_PW_COOP
+#define CPT_PW_COOP 0         // 1: exact walk of scenes larger than the cache fetches missing node records wave-cooperatively
+#endif
+#ifndef CPT_PW_STAGE
+#define CPT_PW_STAGE 16       // staging slots per wave of the cooperative record fetch (a multiple of 8)
+#endif
+
+// How an instance of the persistent kernel divides the CU's 160 KB of LDS.
+//   RESIDENT (the scene lives in the cache whole) and F32: 64 KB of records, 12 node-stack entries and 10 parked
+//   leaves per lane.
+//   Exact walk of a larger scene (COOP): node records that are not cached are fetched by the wave as a whole, eight
+//   lanes per record, one full 128-byte line per record (see the box phase), into CPT_PW_STAGE slots per wave at the
+//   end of the cache planes.  The room comes from shorter LDS lists (8 + 8 entries per lane; deeper stack entries
+//   already go to global memory), and since no plane stores the never-read eighth piece of a record the planes hold
+//   more cached records than before on top of the staging slots.
+template <bool RESIDENT, bool F32>
+struct PwPlan {
+    static constexpr bool COOP = CPT_PW_COOP && !RESIDENT && !F32;
+    static constexpr int STACK_LDS = COOP ? CPT_PW_STACK_LDS_LARGE_HOST : CPT_PW_STACK_LDS_HOST;  // node-stack entries per lane in LDS
+    static constexpr int LEAF_CAP = COOP ? 8 : 10;   // parked leaves per lane (a node expansion adds at most two)
+    static constexpr int STAGE = COOP ? CPT_PW_STAGE : 0;
+    static constexpr int LIST_BYTES = CPT_PW_WAVES * (STACK_LDS + LEAF_CAP) * CPT_WAVE * 4 + (COOP ? CPT_PW_WAVES * CPT_PW_STAGE * 4 : 0);
+    // planar layouts: slots per plane, odd so that the eight pieces of one record fall into eight different bank groups
+    static constexpr int PLANE_SLOTS_RAW = COOP ? (160 * 1024 - 256 - LIST_BYTES) / 112 : CPT_PW_PLANAR_SLOTS_HOST;
+    static constexpr int PLANE_SLOTS = (PLANE_SLOTS_RAW & 1) ? PLANE_SLOTS_RAW : PLANE_SLOTS_RAW - 1;
+    static constexpr int PLANE_BYTES = PLANE_SLOTS * 16;
+    static constexpr int CACHED_SLOTS = F32 ? CPT_PW_CACHE_RECORDS : PLANE_SLOTS - CPT_PW_WAVES * STAGE;  // record slots of the cache proper
+    static constexpr int STAGE_FIRST = CACHED_SLOTS;  // the staging slots follow the cached ones in every plane
+    static constexpr int CACHE_BYTES = COOP ? 7 * PLANE_BYTES : CPT_PW_CACHE_RECORDS * 128;
+    static_assert(7 * PLANE_BYTES <= CACHE_BYTES, "the seven planes must fit the cache");
+    static_assert(CACHE_BYTES + LIST_BYTES <= 160 * 1024, "LDS budget of one workgroup");
+    static_assert(STAGE % 8 == 0, "a load instruction stages eight records");
+};
+static_assert(PwPlan<true, false>::STACK_LDS == CPT_PW_STACK_LDS_HOST && PwPlan<false, false>::STACK_LDS >= CPT_PW_STACK_LDS_LARGE_HOST,
+              "stack split must match the spill buffer sizing");
+static_assert(PwPlan<true, false>::CACHED_SLOTS == CPT_PW_PLANAR_SLOTS_HOST, "the host decides residency by this number");
 
 struct Rec7 {  // the first seven 16-byte pieces of a 128-byte record
     double2 p0, p1, p2, p3, p4, p5, p6;
@@ -240,23 +275,33 @@ __device__ __forceinline__ double2 lds_piece(const lds_byte* p) {
     v2d v = *(const lds_v2d*)p;
     return make_double2(v.x, v.y);
 }
-// PLANAR: the cache holds piece k of slot s at k * CPT_PW_PLANE_BYTES + s * 16 (seven planes of 16-byte pieces; the
-// eighth piece of a record is never read): one address per fetch, the planes are reached through the instruction's
-// offset field, and lanes reading different slots spread over the banks without any swizzle.
-#define CPT_PW_PLANE_SLOTS CPT_PW_PLANAR_SLOTS_HOST  // 585: seven planes of that many 16-byte pieces are the cache's 64 KB
-#define CPT_PW_PLANE_BYTES (CPT_PW_PLANE_SLOTS * 16)
-static_assert(7 * CPT_PW_PLANE_BYTES <= CPT_PW_CACHE_RECORDS * 128, "the seven planes must fit the cache");
-template <bool RESIDENT, bool PLANAR>
+// Planar cache: piece k of slot s at k * PLANE_BYTES + s * 16 (seven planes of 16-byte pieces; the eighth piece of a
+// record is never read): one address per fetch, the planes are reached through the instruction's offset field, and
+// lanes reading different slots spread over the banks without any swizzle.
+template <int PLANE_BYTES>
+__device__ __forceinline__ Rec7 planar_record(const lds_byte* cache, uint32_t slot) {
+    Rec7 r;
+    const lds_byte* rec = cache + slot * 16u;
+    r.p0 = lds_piece(rec); r.p1 = lds_piece(rec + PLANE_BYTES);
+    r.p2 = lds_piece(rec + 2 * PLANE_BYTES); r.p3 = lds_piece(rec + 3 * PLANE_BYTES);
+    r.p4 = lds_piece(rec + 4 * PLANE_BYTES); r.p5 = lds_piece(rec + 5 * PLANE_BYTES);
+    r.p6 = lds_piece(rec + 6 * PLANE_BYTES);
+    return r;
+}
+__device__ __forceinline__ Rec7 global_record(const void* __restrict__ base, int idx) {
+    Rec7 r;
+    const double2* g = (const double2*)((const unsigned char*)base + (size_t)idx * 128);
+    r.p0 = g[0]; r.p1 = g[1]; r.p2 = g[2]; r.p3 = g[3]; r.p4 = g[4]; r.p5 = g[5]; r.p6 = g[6];
+    return r;
+}
+// PLANE_BYTES > 0: planar cache; 0: whole 128-byte records, their pieces rotated by an XOR with (slot >> 1) & 7.
+template <bool RESIDENT, int PLANE_BYTES>
 __device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, const lds_byte* cache, int cache_first,
                                              int cached, int idx) {
-    Rec7 r;
-    if (PLANAR && (RESIDENT || idx < cached)) {
-        const lds_byte* rec = cache + (uint32_t)(cache_first + idx) * 16u;
-        r.p0 = lds_piece(rec); r.p1 = lds_piece(rec + CPT_PW_PLANE_BYTES);
-        r.p2 = lds_piece(rec + 2 * CPT_PW_PLANE_BYTES); r.p3 = lds_piece(rec + 3 * CPT_PW_PLANE_BYTES);
-        r.p4 = lds_piece(rec + 4 * CPT_PW_PLANE_BYTES); r.p5 = lds_piece(rec + 5 * CPT_PW_PLANE_BYTES);
-        r.p6 = lds_piece(rec + 6 * CPT_PW_PLANE_BYTES);
+    if (PLANE_BYTES > 0 && (RESIDENT || idx < cached)) {
+        return planar_record<PLANE_BYTES ? PLANE_BYTES : 16>(cache, (uint32_t)(cache_first + idx));
     } else if (RESIDENT || idx < cached) {
+        Rec7 r;
         const uint32_t slot = (uint32_t)(cache_first + idx);
         const lds_byte* rec = cache + slot * 128u;
         const uint32_t z = (slot >> 1) & 7u;
@@ -264,11 +309,9 @@ __device__ __forceinline__ Rec7 fetch_record(const void* __restrict__ base, cons
         r.p2 = lds_piece(rec + ((2u ^ z) << 4)); r.p3 = lds_piece(rec + ((3u ^ z) << 4));
         r.p4 = lds_piece(rec + ((4u ^ z) << 4)); r.p5 = lds_piece(rec + ((5u ^ z) << 4));
         r.p6 = lds_piece(rec + ((6u ^ z) << 4));
-    } else {
-        const double2* g = (const double2*)((const unsigned char*)base + (size_t)idx * 128);
-        r.p0 = g[0]; r.p1 = g[1]; r.p2 = g[2]; r.p3 = g[3]; r.p4 = g[4]; r.p5 = g[5]; r.p6 = g[6];
+        return r;
     }
-    return r;
+    return global_record(base, idx);
 }
 
 struct Rec4f {  // a 64-byte binary32 node record as four 16-byte pieces
@@ -313,7 +356,7 @@ struct __attribute__((aligned(64))) Node32 {
     // pairs (left child, right child): lo.x, lo.y | lo.z, hi.x | hi.y, hi.z; each pair is one packed-fp32 operand
     float lox[2], loy[2], loz[2], hix[2], hiy[2], hiz[2];
     int32_t lref, rref;
-    int32_t pad_[2];
+    int32_t lid, rid;  // canonical ids of the children (visit-set reporting only)
 };
 static_assert(sizeof(Node32) == 64, "Node32 is half a node record");
 __device__ __forceinline__ float f32_down(double x) {  // largest float <= x
@@ -341,7 +384,7 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_nodes32(const cpt_node* __restric
         r.hiy[0] = plane_up(nd.lbox[4]); r.hiy[1] = plane_up(nd.rbox[4]);
         r.hiz[0] = plane_up(nd.lbox[5]); r.hiz[1] = plane_up(nd.rbox[5]);
         r.lref = nd.lref; r.rref = nd.rref;
-        r.pad_[0] = r.pad_[1] = 0;
+        r.lid = nd.lid; r.rid = nd.rid;
         out[k] = r;
     }
 }
@@ -410,10 +453,16 @@ __device__ __forceinline__ void slab32_pair(v2f lox, v2f loy, v2f loz, v2f hix, 
 template <bool COUNT, bool CULL, bool RESIDENT, bool F32>
 __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStream in, HitBuf hit,
                                                               const uint32_t* __restrict__ counter, uint32_t* cursor, uint32_t cap,
-                                                              uint32_t chunk, uint32_t refill_at, uint32_t leaf_go, uint32_t full_go, uint32_t* spill, unsigned long long* work) {
-    __shared__ __attribute__((aligned(128))) unsigned char s_cache[CPT_PW_CACHE_RECORDS * 128];
-    __shared__ uint32_t s_nodes[CPT_PW_WAVES][CPT_PW_STACK_LDS][CPT_WAVE];
-    __shared__ uint32_t s_leaves[CPT_PW_WAVES][CPT_PW_LEAF_CAP][CPT_WAVE];
+                                                              uint32_t chunk, uint32_t refill_at, uint32_t leaf_go, uint32_t full_go, uint32_t* spill, unsigned long long* work,
+                                                              ExtendObserve obs) {
+    typedef PwPlan<RESIDENT, F32> Plan;
+    constexpr bool COOP = Plan::COOP;
+    constexpr int kStackLds = Plan::STACK_LDS, kLeafCap = Plan::LEAF_CAP;
+    constexpr int kPlaneBytes = F32 ? 0 : Plan::PLANE_BYTES;  // 0: whole records with rotated pieces (fetch_record)
+    __shared__ __attribute__((aligned(128))) unsigned char s_cache[Plan::CACHE_BYTES];
+    __shared__ uint32_t s_nodes[CPT_PW_WAVES][kStackLds][CPT_WAVE];
+    __shared__ uint32_t s_leaves[CPT_PW_WAVES][kLeafCap][CPT_WAVE];
+    __shared__ uint32_t s_missing[COOP ? CPT_PW_WAVES * Plan::STAGE : 1];  // COOP: node indices of the records a wave is staging
     const uint32_t lane = threadIdx.x & (CPT_WAVE - 1), wave = threadIdx.x / CPT_WAVE;
     const uint64_t lanes_below = (1ull << lane) - 1ull;
     // lengths of the stream's segments, one per lane of every wave (lanes beyond the segments hold 0)
@@ -431,7 +480,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     // (F32: 64-byte binary32 node records, twice as many per byte; triangle records start at the next 128-byte slot)
     // A scene that does not fit whole keeps CPT_PW_HOT_TRIS slots for its first triangles, which the library has put
     // largest bounding box first: those few take most of the triangle tests.
-    constexpr int kSlots = F32 ? CPT_PW_CACHE_RECORDS : CPT_PW_PLANE_SLOTS;  // record slots of this variant's cache layout
+    constexpr int kSlots = Plan::CACHED_SLOTS;  // record slots of this instance's cache layout
     const bool fits = (F32 ? (sc.n_nodes + 1) / 2 : sc.n_nodes) + sc.n_tris <= kSlots;
     const int tri_reserve = fits ? 0 : (sc.n_tris < CPT_PW_HOT_TRIS ? sc.n_tris : CPT_PW_HOT_TRIS);
     const int node_room = F32 ? (kSlots - tri_reserve) * 2 : kSlots - tri_reserve;
@@ -455,7 +504,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
             int r = i >> 3, c = i & 7;
             const unsigned char* src = r < cached_nodes ? (const unsigned char*)sc.nodes + (size_t)r * 128
                                                         : (const unsigned char*)sc.tris + (size_t)(r - cached_nodes) * 128;
-            if (c < 7) *(double2*)(s_cache + (size_t)c * CPT_PW_PLANE_BYTES + (size_t)r * 16) = *(const double2*)(src + c * 16);  // planar, see fetch_record
+            if (c < 7) *(double2*)(s_cache + (size_t)c * Plan::PLANE_BYTES + (size_t)r * 16) = *(const double2*)(src + c * 16);  // planar, see planar_record
         }
     }
     // the largest plane magnitude of the scene (the root's two child boxes contain everything): scale of the
@@ -467,6 +516,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
         for (int k = 0; k < 12; ++k) m = fmax(m, fabs(b[k]));
         scene_extent = f32_up(m);
     }
+    if (COOP && threadIdx.x < CPT_PW_WAVES * Plan::STAGE) s_missing[threadIdx.x] = 0u;
     __syncthreads();
     const lds_byte* cache = (const lds_byte*)s_cache;
 
@@ -476,6 +526,9 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     lds_u32* const leaf_base = (lds_u32*)&s_leaves[wave][0][lane];  // entries are CPT_WAVE words apart
     lds_u32* leaf_top = leaf_base;
 #define CPT_LEAVES_AT_MOST(N) (leaf_top <= leaf_base + (N) * CPT_WAVE)
+    // COOP: this wave's staging slots in the cache planes and the list of node indices being staged
+    lds_u32* const missing = (lds_u32*)&s_missing[COOP ? wave * Plan::STAGE : 0];
+    const uint32_t stage_first = (uint32_t)Plan::STAGE_FIRST + wave * (uint32_t)Plan::STAGE;
     // likewise the node stack of the RESIDENT instances (the others count entries: theirs continues in global memory)
     lds_u32* const node_base = (lds_u32*)&s_nodes[wave][0][lane];
     lds_u32* node_top = node_base;
@@ -495,6 +548,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     int best_tri = -1;
     uint32_t best_rank = 0xFFFFFFFFu;
     unsigned long long steps = 0, tris = 0, exact = 0, box_passes = 0, leaf_passes = 0;
+    unsigned long long vhash = 0;  // COUNT: order-free hash of the canonical ids of the nodes whose boxes this lane's ray has tested
 
     for (;;) {
         // ---- refill idle lanes ----
@@ -526,6 +580,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 best_t = -1.0;
                 best_tri = -1;
                 best_rank = 0xFFFFFFFFu;
+                if (COUNT) vhash = 0;
                 sp = 0;
                 node_top = node_base;
                 leaf_top = leaf_base;
@@ -551,17 +606,57 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
         // decisions -- over more node steps)
 #pragma unroll
         for (int rep = 0; rep < CPT_PW_BOX_REPEAT; ++rep) {
+            const bool boxing = node >= 0 && CPT_LEAVES_AT_MOST(kLeafCap - 2);
             if (COUNT) {
-                uint64_t boxing = __ballot(node >= 0 && CPT_LEAVES_AT_MOST(CPT_PW_LEAF_CAP - 2));
-                if (lane == 0 && boxing) box_passes++;
+                uint64_t any_boxing = __ballot(boxing);
+                if (lane == 0 && any_boxing) box_passes++;
             }
-            if (node >= 0 && CPT_LEAVES_AT_MOST(CPT_PW_LEAF_CAP - 2)) {
+            // COOP: node records that are not in the cache are fetched by the wave as a whole.  A lane loading its own
+            // record issues seven 16-byte loads on a 128-byte line no other lane touches, so a pass with m such lanes
+            // costs the CU's one vector-memory address unit 7 m line look-ups (it was busy 65 % of the time on a
+            // 10 000-triangle scene, with the waves parked behind it).  Here the lanes that miss publish their node
+            // index in LDS, every group of eight lanes loads one of those records as one contiguous 128-byte line
+            // (lane p of the group its piece p) and writes it to the wave's staging slots at the end of the cache
+            // planes, and the lanes that missed then read their record from LDS like a cached one: m look-ups.
+            // A wave's LDS operations complete in order, so the hand-over needs no barrier.
+            uint32_t slot = (uint32_t)node;
+            bool direct = false;
+            if (COOP) {
+                const bool miss = boxing && node >= cached_nodes;
+                const uint64_t mm = __ballot(miss);
+                if (mm) {
+                    const uint32_t rank = (uint32_t)__popcll(mm & lanes_below), n_miss = (uint32_t)__popcll(mm);
+                    if (miss && rank < (uint32_t)Plan::STAGE) missing[rank] = (uint32_t)node;
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t group = lane >> 3, piece = lane & 7u;
+                    if (piece < 7u) {
+                        v2d staged[Plan::STAGE / 8 > 0 ? Plan::STAGE / 8 : 1];
+#pragma unroll
+                        for (int k = 0; k < Plan::STAGE / 8; ++k) {
+                            const uint32_t j = group + 8u * k;
+                            const uint32_t idx = j < n_miss ? missing[j] : 0u;  // spare groups all read record 0: one line
+                            staged[k] = *(const v2d*)((const unsigned char*)sc.nodes + (size_t)idx * 128 + piece * 16u);
+                        }
+#pragma unroll
+                        for (int k = 0; k < Plan::STAGE / 8; ++k)
+                            *(lds_v2d*)((lds_byte*)s_cache + piece * (uint32_t)Plan::PLANE_BYTES + (stage_first + group + 8u * k) * 16u) = staged[k];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (miss) {
+                        if (rank < (uint32_t)Plan::STAGE) slot = stage_first + rank;
+                        else direct = true;  // more misses than staging slots: these lanes fetch their own record
+                    }
+                }
+            }
+            if (boxing) {
                 int2 refs;  // lref, rref
+                int2 ids;   // COUNT: canonical ids of the two children
                 bool hl, hr;
                 double enter_l, enter_r;
                 if (F32) {
                     const Rec4f r = fetch_node32<RESIDENT>(sc.nodes32, cache, cached_nodes, node);
                     refs = make_int2(__float_as_int(r.p3.x), __float_as_int(r.p3.y));
+                    ids = make_int2(__float_as_int(r.p3.z), __float_as_int(r.p3.w));
                     float el, er;
                     v2f lox = {r.p0.x, r.p0.y}, loy = {r.p0.z, r.p0.w}, loz = {r.p1.x, r.p1.y};
                     v2f hix = {r.p1.z, r.p1.w}, hiy = {r.p2.x, r.p2.y}, hiz = {r.p2.z, r.p2.w};
@@ -569,8 +664,11 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                     enter_l = (double)el;
                     enter_r = (double)er;
                 } else {
-                    Rec7 r = fetch_record<RESIDENT, true>(sc.nodes, cache, 0, cached_nodes, node);
+                    Rec7 r;
+                    if (COOP) r = direct ? global_record(sc.nodes, node) : planar_record<kPlaneBytes ? kPlaneBytes : 16>(cache, slot);
+                    else r = fetch_record<RESIDENT, kPlaneBytes>(sc.nodes, cache, 0, cached_nodes, node);
                     refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));
+                    ids = make_int2(__double2loint(r.p6.y), __double2hiint(r.p6.y));
                     bool sure_l, sure_r;
                     hl = slab_filtered(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, sr, sure_l, enter_l);
                     hr = slab_filtered(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, sr, sure_r, enter_r);
@@ -578,6 +676,14 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                         if (COUNT) exact++;
                         hl = slab_hit(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, d, enter_l);
                         hr = slab_hit(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, d, enter_r);
+                    }
+                }
+                if (COUNT) {  // both child boxes have been tested (reference: src/gpu/GPUBVH.cu:56-57), whatever the walk does next
+                    vhash += visit_mix((uint32_t)ids.x) + visit_mix((uint32_t)ids.y);
+                    if (obs.bitmap) {
+                        uint8_t* row = obs.bitmap + (size_t)pos * (size_t)obs.bitmap_stride;
+                        row[ids.x >> 3] |= (uint8_t)(1u << (ids.x & 7));
+                        row[ids.y >> 3] |= (uint8_t)(1u << (ids.y & 7));
                     }
                 }
                 if (CULL) {
@@ -613,16 +719,16 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 } else if (tl) {
                     node = refs.x;
                     if (tr) {
-                        if (sp < CPT_PW_STACK_LDS) my_nodes[sp * CPT_WAVE] = (uint32_t)refs.y;
-                        else my_spill[(size_t)(sp - CPT_PW_STACK_LDS) * spill_stride] = (uint32_t)refs.y;
+                        if (sp < kStackLds) my_nodes[sp * CPT_WAVE] = (uint32_t)refs.y;
+                        else my_spill[(size_t)(sp - kStackLds) * spill_stride] = (uint32_t)refs.y;
                         ++sp;
                     }
                 } else if (tr) {
                     node = refs.y;
                 } else if (sp > 0) {
                     --sp;
-                    if (sp < CPT_PW_STACK_LDS) node = (int)my_nodes[sp * CPT_WAVE];
-                    else node = (int)my_spill[(size_t)(sp - CPT_PW_STACK_LDS) * spill_stride];
+                    if (sp < kStackLds) node = (int)my_nodes[sp * CPT_WAVE];
+                    else node = (int)my_spill[(size_t)(sp - kStackLds) * spill_stride];
                 } else {
                     node = -1;
                 }
@@ -633,13 +739,13 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
         uint64_t have_leaf = __ballot(leaf_top != leaf_base);
         if (have_leaf) {
             uint64_t have_node = __ballot(node >= 0);
-            uint64_t nearly_full = __ballot(!CPT_LEAVES_AT_MOST(CPT_PW_LEAF_CAP - 2));
+            uint64_t nearly_full = __ballot(!CPT_LEAVES_AT_MOST(kLeafCap - 2));
             if ((uint32_t)__popcll(have_leaf) >= leaf_go || (have_node & ~nearly_full) == 0 || (uint32_t)__popcll(nearly_full) >= full_go) {
                 if (COUNT && lane == 0) leaf_passes++;
                 if (leaf_top != leaf_base) {
                     leaf_top -= CPT_WAVE;
                     int tri = (int)~*leaf_top;
-                    Rec7 q = fetch_record<RESIDENT, !F32>(sc.tris, cache, tri_first, cached_tris, tri);
+                    Rec7 q = fetch_record<RESIDENT, kPlaneBytes>(sc.tris, cache, tri_first, cached_tris, tri);
                     uint32_t flags = (uint32_t)__double2hiint(q.p6.x), rank = (uint32_t)__double2loint(q.p6.y);
                     bool gate = true;
                     if (F32 && sc.n_nodes > 0) {  // (a one-triangle scene has no boxes at all) the exact test of the leaf's own box: the bounds of the three vertices (reference: src/scene/bvh.cpp:128-146)
@@ -669,6 +775,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
         // ---- retire ----
         if (has_ray && node < 0 && leaf_top == leaf_base) {
             store_hit(hit, pos, best_t, best_tri);
+            if (COUNT && obs.vhash) obs.vhash[pos] = vhash;
             has_ray = false;
         }
     }
@@ -929,18 +1036,18 @@ void launch_dense_counts(const LaunchCfg& L, uint32_t* counts, uint32_t n, uint3
     hipLaunchKernelGGL(k_dense_counts, dim3(1), dim3(64), 0, L.stream, counts, n, cap);
 }
 void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
-                   uint32_t cap, long long max_entries, unsigned long long* work) {
+                   uint32_t cap, long long max_entries, unsigned long long* work, const ExtendObserve& obs) {
     int g = grid_for(max_entries, L.max_blocks);
-    if (work) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, in, hit, counter, cap, work);
-    else hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, in, hit, counter, cap, work);
+    if (work) hipLaunchKernelGGL(k_extend<true>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, in, hit, counter, cap, work, obs);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, in, hit, counter, cap, work, obs);
 }
 void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
-                      uint32_t cap, uint32_t* cursor, uint32_t* spill, unsigned long long* work) {
+                      uint32_t cap, uint32_t* cursor, uint32_t* spill, unsigned long long* work, const ExtendObserve& obs) {
     int g = L.pw_blocks;
 #define CPT_PW_LAUNCH(COUNT, CULL, RES, F32)                                                                                  \
     hipLaunchKernelGGL((k_extend_pw<COUNT, CULL, RES, F32>), dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, \
                        cursor, cap, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go,                       \
-                       (uint32_t)L.pw_full_go, spill, work)
+                       (uint32_t)L.pw_full_go, spill, work, obs)
     const bool resident = L.pw_resident != 0;
     const int which = (L.pw_f32 ? 8 : 0) | (work ? 4 : 0) | (L.pw_cull ? 2 : 0) | (resident ? 1 : 0);
     switch (which) {

@@ -119,8 +119,12 @@ struct Radiance {           // radiance gathered per path, indexed by slot; touc
 };
 #define CPT_SLOT_BYTES (2 * CPT_STREAM_BYTES + 16 + 24)  // device bytes per path slot of a batch: two streams, hit record, radiance
 
-// traversal stack of the persistent-wave extend kernel: entries in LDS, and the deepest tree it accepts
+// traversal stack of the persistent-wave extend kernel: entries in LDS, and the deepest tree it accepts.  The instances
+// for scenes that live in the record cache whole keep CPT_PW_STACK_LDS_HOST entries per lane in LDS and have no spill
+// path; the instances for larger scenes keep CPT_PW_STACK_LDS_LARGE_HOST (their LDS also holds the staging slots of
+// the wave-cooperative record fetch) and continue in a per-lane column of global memory.
 #define CPT_PW_STACK_LDS_HOST 12
+#define CPT_PW_STACK_LDS_LARGE_HOST 8
 #define CPT_PW_STACK_MAX 62
 // The rays of a stream are handed to the persistent extend kernel's waves in small chunks.  One claim
 // counter for the whole stream would serialise the claims (an address takes on the order of 10^8
@@ -135,6 +139,15 @@ inline size_t cpt_stream_positions(size_t n) { return (size_t)cpt_segment_cap(n)
 #define CPT_PW_CACHE_RECORDS_HOST 512  // 128-byte records of the scene the persistent extend kernel keeps in LDS (its 64 KB record cache) ...
 #define CPT_PW_PLANAR_SLOTS_HOST 585   // ... and how many the exact variants keep, which store only the seven 16-byte pieces of a record that are ever read
 #define CPT_PW_THREADS_HOST 1024
+
+// What the counting instances of the extend kernels can report per ray besides the hit (all nullable; indexed by
+// stream position): the order-free hash of the canonical ids of every node whose box was tested, and one bitmap row
+// per ray with a bit per canonical id.  The parity hooks fill it in; the render path passes an empty one.
+struct ExtendObserve {
+    unsigned long long* vhash;
+    uint8_t* bitmap;
+    int bitmap_stride;
+};
 
 struct LaunchCfg {
     hipStream_t stream;
@@ -154,9 +167,9 @@ void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, con
 void launch_nodes32(hipStream_t st, const cpt_node* d_nodes, int n_nodes, void* d_nodes32);
 void launch_dense_counts(const LaunchCfg& L, uint32_t* counts, uint32_t n, uint32_t cap);
 void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
-                   uint32_t cap, long long max_entries, unsigned long long* work);
+                   uint32_t cap, long long max_entries, unsigned long long* work, const ExtendObserve& obs);
 void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
-                      uint32_t cap, uint32_t* cursor, uint32_t* spill, unsigned long long* work);
+                      uint32_t cap, uint32_t* cursor, uint32_t* spill, unsigned long long* work, const ExtendObserve& obs);
 void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& in, const HitBuf& hit,
                   const RayStream& out, const Radiance& col, int batch_s0, int bounce, const uint32_t* counter_in,
                   uint32_t* counter_out, uint32_t cap, long long max_entries, unsigned long long* work);

@@ -158,6 +158,21 @@ class Renderer:
                     "cpt_extend_rays")
         return tri, t
 
+    def extend_rays_observed(self, origins, dirs, bitmap=False):
+        """extend_rays through the kernel's counting instance: dict with prim, t, vhash (order-free hash of the
+        canonical ids of the nodes whose boxes each ray's walk tested) and, on request, one visit bitmap row per ray."""
+        o = np.ascontiguousarray(origins, np.float64)
+        d = np.ascontiguousarray(dirs, np.float64)
+        n = o.shape[0]
+        tri = np.empty(n, np.int32)
+        t = np.empty(n, np.float64)
+        vh = np.zeros(n, np.uint64)
+        stride = (self._scene.n_tree_nodes + 7) // 8 if self._scene is not None else 0
+        bm = np.zeros((n, stride), np.uint8) if bitmap else None
+        self._check(self._L.cpt_extend_rays_observed(self._h, n, _vp(o), _vp(d), _vp(tri), _vp(t), _vp(vh), _vp(bm), stride),
+                    "cpt_extend_rays_observed")
+        return dict(prim=tri, t=t, vhash=vh, bitmap=bm)
+
     def trace_rays(self, origins, dirs, bitmap=False):
         o = np.ascontiguousarray(origins, np.float64)
         d = np.ascontiguousarray(dirs, np.float64)

@@ -212,7 +212,7 @@ int cpt_render(cpt_ctx* ctx, const cpt_render_params* params, double* d_accum);
  * library's device code, so the call makes no hipMalloc / hipFree and creates no events or streams.  It has no
  * counterpart in the reference (whose render path allocates per object, src/gpu/GPUManaged.cuh:19-24).
  * Limits: one sample of the tile window must fit, i.e.
- *   2 * 2 KB * (depth + 2)  +  4 KB * CUs * max(0, tree height - 14)  +  208 B * (pixels of the window, in whole 8x8 tiles)
+ *   2 * 2 KB * (depth + 2)  +  4 KB * CUs * max(0, tree height - 10)  +  208 B * (pixels of the window, in whole 8x8 tiles)
  * must not exceed CPT_NOALLOC_SCRATCH_BYTES (a 512x512 image at any accepted tree height does; a 1024x1024 image is
  * rendered as four tile windows); otherwise CPT_ELIMIT.  Samples are rendered in as large batches as fit, one batch
  * at a time on the context's stream; instrumentation settings are ignored.  Every context on a GPU shares that
@@ -263,6 +263,15 @@ int cpt_reset_stats(cpt_ctx* ctx);
  * Observes the extend half of pathTrace (reference: src/improved_path_tracer.cu:60-75), which calls
  * GPU::BVH::traverseIterative (src/gpu/GPUBVH.cu:38-99). */
 int cpt_extend_rays(cpt_ctx* ctx, int32_t n, const double* h_origin, const double* h_dir, int32_t* h_tri, double* h_t);
+
+/* cpt_extend_rays through the counting instance of that same kernel, which also reports, per ray, what its walk
+ * touched: h_visit_hash n (nullable; sum over the nodes whose box was tested of mix64(canonical id + 1), the same
+ * order-free hash cpt_trace_rays reports) and h_bitmap (nullable) n rows of bitmap_stride bytes with bit k set iff
+ * node k's box was tested.  For extend variants 0 and 1 both equal the reference walk's; variants 3 and 4 test a
+ * superset of inner boxes, 2 and 4 skip culled subtrees.
+ * Observes GPU::BVH::traverseIterative (reference: src/gpu/GPUBVH.cu:38-99) as the render path runs it. */
+int cpt_extend_rays_observed(cpt_ctx* ctx, int32_t n, const double* h_origin, const double* h_dir, int32_t* h_tri, double* h_t,
+                             uint64_t* h_visit_hash, uint8_t* h_bitmap, int32_t bitmap_stride);
 
 /* Intersect n explicit rays with the scene using exactly the render path's traversal.
  * Host arrays: h_origin/h_dir n*3 doubles.  Outputs (host): h_tri n (triangle index or -1),

@@ -349,6 +349,80 @@ def test_pipeline_extend_kernel_on_explicit_rays_bit_exact(name, gpu_scene, orac
         g.reset_stats()
 
 
+@pytest.mark.parametrize("name", SCENES)
+def test_render_extend_kernel_visit_sets_bit_exact(name, gpu_scene, oracle_scenes):
+    """The visit set of GPU::BVH::traverseIterative (reference: src/gpu/GPUBVH.cu:38-99), reported per ray by the
+    extend kernel the renderer launches (its counting instance): the order-free hash over the canonical ids of every
+    node whose box was tested equals the oracle's for the one-ray-per-thread kernel and for the persistent kernel's
+    reference walk (variants 0 and 1), on camera rays, random rays, tie-prone rays (aimed at box corners, starting
+    on box planes) and axis-parallel rays; hit triangle and t bits likewise.  On one scene also bitmap against bitmap."""
+    g = gpu_scene(name)
+    orc = oracle_scenes(name)
+    rng = np.random.default_rng(17)
+    boxes, _ = orc.nodes()
+    lo, hi = boxes[0, :3], boxes[0, 3:]
+    n = 12000
+    o1 = rng.uniform(lo - 0.1 * (hi - lo), hi + 0.1 * (hi - lo), (n, 3))
+    d1 = rng.normal(size=(n, 3))
+    d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
+    o2, d2 = _tie_prone_rays(orc, rng, n)
+    o3, d3 = orc.camera_rays(64, 64)
+    o = np.concatenate([o1, o2, o3])
+    d = np.concatenate([d1, d2, d3])
+    want = orc.trace(o, d, bitmap=(name == "teapot-trans"))
+    assert len(np.unique(want["vhash"])) > 100
+    try:
+        for variant in (1, 0):
+            g.set_option("extend_variant", variant)
+            got = g.extend_rays_observed(o, d, bitmap=(name == "teapot-trans"))
+            assert np.array_equal(got["prim"], want["prim"]), "hit triangle ids differ (variant %d)" % variant
+            assert np.array_equal(bits(got["t"]), bits(want["t"])), "hit distances differ (variant %d)" % variant
+            assert np.array_equal(got["vhash"], want["vhash"]), "visited-node sets differ (variant %d)" % variant
+            if got["bitmap"] is not None:
+                assert np.array_equal(got["bitmap"], want["bitmap"]), "visit bitmaps differ (variant %d)" % variant
+    finally:
+        g.set_option("extend_variant", 1)
+
+
+def test_fast_walks_visit_supersets_and_subsets(gpu_scene, oracle_scenes):
+    """What the non-reference walks touch, per ray, as bitmaps: the binary32 inner-node test (variant 3) is conservative, so it
+    tests every box the reference tests and a few more; the culling walk (variant 2) tests only boxes the reference tests.
+    Hits are the reference's in both."""
+    g = gpu_scene("dragon-spec")
+    orc = oracle_scenes("dragon-spec")
+    rng = np.random.default_rng(23)
+    boxes, _ = orc.nodes()
+    lo, hi = boxes[0, :3], boxes[0, 3:]
+    n = 3000
+    o = rng.uniform(lo - 0.1 * (hi - lo), hi + 0.1 * (hi - lo), (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    oc, dc = orc.camera_rays(32, 32)
+    o, d = np.concatenate([o, oc]), np.concatenate([d, dc])
+    want = orc.trace(o, d, bitmap=True)
+    try:
+        for variant in (3, 2, 4):
+            g.set_option("extend_variant", variant)
+            got = g.extend_rays_observed(o, d, bitmap=True)
+            assert np.array_equal(got["prim"], want["prim"]) and np.array_equal(bits(got["t"]), bits(want["t"]))
+            extra = got["bitmap"] & ~want["bitmap"]
+            lost = want["bitmap"] & ~got["bitmap"]
+            if variant == 3:
+                assert not lost.any(), "the binary32 walk skipped a box the reference tests"
+                # "a few": the margins are absolute in position (2^-20 of the scene's extent), so a ray that barely moves
+                # on an axis (this camera's middle columns: origin x = 0, direction x near 0) is loose on that axis; the
+                # random rays, whose directions have no such axis, stay within a few per cent
+                n_extra = int(np.unpackbits(extra[:n]).sum()), int(np.unpackbits(want["bitmap"][:n]).sum())
+                assert n_extra[0] <= 0.03 * n_extra[1], n_extra
+            elif variant == 2:
+                assert not extra.any(), "the culling walk tested a box the reference does not"
+                assert lost.any()
+            else:
+                assert lost.any()
+    finally:
+        g.set_option("extend_variant", 1)
+
+
 def test_edge_cases(gpu, host_scenes, oracle):
     import torch
     from cuda_path_tracer_amd import HostScene
