@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the path-tracing hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|dragon|teapot_dof|cornell2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|dragon|teapot_dof|cornell2|cfg4|cfg5_cornell|cfg5_dragon]
                     [--extra dragon,teapot_dof|none] [--scaling weak|strong]
 
 A step renders the whole workload once (all samples of every pixel of every scene in it) with the
@@ -14,7 +14,10 @@ With N > 1 there is one rank per GPU (under torch.distributed.run; run as plain 
 starts that launcher itself, before anything touches a GPU).  Ranks render disjoint shares of the same image and
 the per-rank fp64 radiance sums are reduced to rank 0 over RCCL: `--scaling weak` gives every rank the workload's
 sample count as new sample indices (per-GPU work fixed), `--scaling strong` deals the workload's samples out
-(total work fixed; by image tiles when there are fewer samples than ranks).  Rank 0 prints one JSON line.
+(total work fixed; by image tiles when there are fewer samples than ranks).  With N > 1 the line also carries, under
+`workloads`, the full-node shapes of BASELINE configs[3] and [4] (cfg4: teapot-trans with the thin lens, 1024x1024, 4096
+spp; cfg5: cornell-box2 512x512 at 16384 spp and dragon-spec 2048x2048 at 8192 spp), always with their fixed totals dealt
+over the N GPUs, each with the slowest rank's render and reduce times.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -31,9 +34,16 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
 # fp64 vector issue peak: 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz lane-instructions per second
 # (the 78.6 TFLOP/s vector fp64 peak counts an FMA as two)
 FP64_ISSUE_PEAK = 256 * 4 * 16 * 2.4e9
-# fp64 VALU instructions per lane on the extend kernel's two hot paths, counted in its ISA by
-# tools/count_fp64_isa.py (output committed as profiles/r02_isa_fp64_counts.txt): the division-free test of both
-# child boxes of a node, and one triangle test that runs through all three edge tests.
+# Algorithmic constants of the roofline's numerator, frozen: fp64 operations per lane of the two units of work the
+# reference walk is made of.  They were counted once in the extend kernel's ISA (tools/count_fp64_isa.py, output
+# committed as profiles/r02_isa_fp64_counts.txt) and are NOT re-counted when the kernel changes, so that adding
+# instructions to the kernel cannot raise `achieved`.
+#   node step = the division-free test of both child boxes, 2 x 35: per box 6 subtractions (plane - origin), 6 products
+#     with the reciprocal direction, 6 min/max (near and far per axis), 3 max (largest near of the other two axes),
+#     1 max (entry distance), 2 min (smallest far), 3 subtractions + 2 min (the gap G), 1 add + 1 fma (the margin),
+#     4 compares.
+#   triangle test that runs through all three edge tests, 89: o - a, two dot products, the division's 13-instruction
+#     expansion, the hit point, three edge vectors, three cross products and three dot products with the normal.
 F64_PER_NODE_STEP = 70
 F64_PER_TRIANGLE_TEST = 89
 
@@ -51,11 +61,26 @@ WORKLOADS = {
     # the size the reference's CPU estimator is quoted on
     "cornell2": dict(desc="cornell-box2, 512x512, 16 spp, depth 5", scenes=["cornell-box2"], width=512, spp=16,
                      depth=5),
+    # BASELINE configs[3] and [4]: fixed totals dealt out over the GPUs of the run (strong scaling whatever --scaling
+    # says), measured by default when N > 1
+    "cfg4": dict(desc="teapot-trans, thin lens (focal distance 8.1, aperture 0.6), 1024x1024, 4096 spp in all, depth 8",
+                 scenes=["teapot-trans"], width=1024, spp=4096, depth=8, scaling="strong",
+                 render=dict(dof=True, focal_distance=8.1, aperture=0.6)),
+    "cfg5_cornell": dict(desc="cornell-box2, 512x512, 16384 spp in all, depth 8", scenes=["cornell-box2"], width=512,
+                         spp=16384, depth=8, scaling="strong"),
+    "cfg5_dragon": dict(desc="dragon-spec, 2048x2048, 8192 spp in all, depth 8", scenes=["dragon-spec"], width=2048,
+                        spp=8192, depth=8, scaling="strong"),
 }
+MULTI_GPU_EXTRAS = "cfg4,cfg5_cornell,cfg5_dragon"
 
 
 if os.environ.get("CPT_BENCH_CORNELL2_SPP"):  # test hook: fewer samples than ranks exercises the tile split
     WORKLOADS["cornell2"]["spp"] = int(os.environ["CPT_BENCH_CORNELL2_SPP"])
+if os.environ.get("CPT_BENCH_SHRINK"):  # test hook: the full-node shapes at 1/k of their width and 1/k^2 of their samples
+    _k = int(os.environ["CPT_BENCH_SHRINK"])
+    for _name in ("cfg4", "cfg5_cornell", "cfg5_dragon"):
+        WORKLOADS[_name]["width"] //= _k
+        WORKLOADS[_name]["spp"] //= _k * _k
 
 
 def scene_file(name):
@@ -242,18 +267,32 @@ class Bench:
             rgb = torch.zeros(h, w, 3, dtype=torch.uint8, device="cuda")
             renderers.append((r, hs, w, h, acc, rgb))
         spp = wl["spp"]
-        total_spp = spp * world if args.scaling == "weak" else spp
+        scaling = wl.get("scaling", args.scaling)
+        total_spp = spp * world if scaling == "weak" else spp
         extra = wl.get("render", {})
+        phase = {"render": 0.0, "reduce": 0.0}
 
-        def step(collective=True):
+        def step(collective=True, clocked=False):
+            """clocked: wait for the render and for the reduce and note how long each took on this rank (the timed steps
+            never do: there the phases of consecutive scenes and steps overlap)."""
             for (r, hs, w, h, acc, rgb) in renderers:
                 acc.zero_()
-                share = shard(rank, world, spp, w, h, args.scaling)
+                if clocked:
+                    torch.cuda.synchronize()
+                    t_a = time.perf_counter()
+                share = shard(rank, world, spp, w, h, scaling)
                 if share is not None:
                     r.render_into(acc.data_ptr(), r.params(w, h, share["sample_begin"], share["sample_end"], wl["depth"], mode=mode,
                                                            tile_begin=share["tile_begin"], tile_count=share["tile_count"], **extra))
+                if clocked:
+                    torch.cuda.synchronize()
+                    t_b = time.perf_counter()
                 if collective:
                     reduce_radiance(acc, dst=0, single_rank_too=self.distributed)
+                if clocked:
+                    torch.cuda.synchronize()
+                    phase["render"] += t_b - t_a
+                    phase["reduce"] += time.perf_counter() - t_b
                 if rank == 0:
                     r.tonemap_into(acc.data_ptr(), w, h, total_spp, rgb.data_ptr())
 
@@ -267,15 +306,25 @@ class Bench:
         self.fence()
         elapsed = time.perf_counter() - t0
         self.say("%s: timed steps done in %.3f s" % (key, elapsed))
+        render_ms = reduce_ms = None
         if self.distributed:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+            # one more step, outside the timed region, with a wait after each phase: the slowest rank's render time and
+            # reduce time (the reduce includes waiting for the slowest rank's render to arrive)
+            step(clocked=True)
+            t = torch.tensor([elapsed, phase["render"], phase["reduce"]], dtype=torch.float64,
+                             device="cuda" if self.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            elapsed, render_ms, reduce_ms = float(t[0]), float(t[1]) * 1e3, float(t[2]) * 1e3
         paths_per_step = sum(w * h * total_spp for (_, _, w, h, _, _) in renderers)  # all ranks together
         rec = None
         if rank == 0:
             rec = {"workload": wl["desc"], "value": steps * paths_per_step / elapsed / 1e6, "unit": "Mpaths/s",
-                   "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "paths_per_step": paths_per_step}
+                   "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "paths_per_step": paths_per_step,
+                   "scaling": scaling, "n_gpus": world}
+            if self.distributed:
+                rec.update({"render_ms": render_ms, "reduce_ms": reduce_ms, "rccl_ranks": self.ranks_seen,
+                            "phase_note": "one extra step with a wait after each phase, max over ranks; reduce_ms includes "
+                                          "waiting for the slowest rank"})
             if with_roofline:
                 rec["roofline"] = self.roofline(key, renderers, step, mode)
         for (r, *_rest) in renderers:
@@ -340,9 +389,16 @@ class Bench:
             # counts by the kernel's ISA) per second of extend-kernel time; peak = every SIMD issuing fp64 every cycle.
             "bound": "fp64_valu_issue", "kernel": "k_extend_pw", "achieved": useful / secs / 1e12,
             "peak": FP64_ISSUE_PEAK / 1e12, "unit": "T fp64 lane-instructions/s", "frac": useful / secs / FP64_ISSUE_PEAK,
+            # the byte yardstick next to it: algorithmic record bytes per second over the HBM peak.  Above 1 means the
+            # records cannot be coming from HBM, and they are not: the kernel serves them from its LDS copy of the scene
+            # (and L2), which is why the byte rate is reported but is not this kernel's bound
+            "hbm_algorithmic_ratio_to_hbm_peak": kbytes / secs / 1e9 / HBM_PEAK_GBPS,
+            "hbm_algorithmic_note": "104 B per node step + 100 B per triangle test + 64 B per segment, per second, over 8 TB/s; "
+                                    "> 1 => served from LDS/L2, not HBM",
             "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": launches,
             "instr_per_node_step": F64_PER_NODE_STEP, "instr_per_triangle_test": F64_PER_TRIANGLE_TEST,
-            "isa_evidence": "profiles/r02_isa_fp64_counts.txt (tools/count_fp64_isa.py)",
+            "instr_constants": "frozen algorithmic constants (minimal fp64 op list in bench.py), first counted in "
+                               "profiles/r02_isa_fp64_counts.txt (tools/count_fp64_isa.py); not re-counted per build",
             "occupied_frac": occupied / secs / FP64_ISSUE_PEAK,
             "lane_slots_used": {"box": agg["node_steps"] / max(64 * agg["box_passes"], 1),
                                 "triangle": agg["tri_tests"] / max(64 * agg["leaf_passes"], 1)},
@@ -367,8 +423,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS), help="the headline workload (`value`)")
-    ap.add_argument("--extra", default="dragon,teapot_dof",
-                    help="comma-separated workloads also measured (2 steps each) and reported under `workloads`; 'none' for none")
+    ap.add_argument("--extra", default=None,
+                    help="comma-separated workloads also measured and reported under `workloads`; 'none' for none.  Default: "
+                         "dragon,teapot_dof (2 steps each) on one GPU; with N > 1 the full-node shapes of BASELINE configs[3] and "
+                         "[4], " + MULTI_GPU_EXTRAS + " (fixed totals dealt over the N GPUs, 1 step each)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank renders the workload's sample count (new sample indices per rank); strong: the "
                          "workload's samples are dealt out over the ranks")
@@ -386,6 +444,8 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.extra is None:
+        args.extra = "dragon,teapot_dof" if args.gpus == 1 else MULTI_GPU_EXTRAS
     names = [] if args.extra in ("", "none") else [n for n in args.extra.split(",") if n and n != args.workload]
     for name in names:
         if name not in WORKLOADS:
@@ -398,13 +458,14 @@ def main():
     head = b.measure(args.workload, args.steps, args.warmup)
     extras = {}
     for name in names:
-        extras[name] = b.measure(name, 2, 1)
+        heavy = WORKLOADS[name].get("scaling") == "strong"  # the full-node shapes: tens of seconds per step on two GPUs
+        extras[name] = b.measure(name, 1 if heavy else 2, 1)
     # The fast modes, beside the numbers above and never instead of them: the same closest hits (so the same image,
     # bit for bit) from a walk that is not the reference's.  3: inner nodes through a conservative binary32 box test,
     # every leaf through the exact test of its own box; 4: the same, nearer child first, boxes beyond the closest hit
     # so far skipped.
     fast = {}
-    if not args.no_fast_modes and args.mode == "wavefront":
+    if not args.no_fast_modes and args.mode == "wavefront" and b.world == 1:
         for name in [args.workload] + names:
             rec = {}
             for label, variant in (("binary32_inner_nodes", 3), ("binary32_inner_nodes_and_culling", 4)):
@@ -420,14 +481,18 @@ def main():
         world = b.world
         out = {"metric": "Mpaths/s", "value": head["value"], "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
-               "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "scaling": wl.get("scaling", args.scaling), "vs_baseline": None, "dtype": "f64",
+               "data": "the reference's bundled scenes (tests/golden/scenes/*.ray: " + ", ".join(
+                   sorted({n for k in [args.workload] + names for n in WORKLOADS[k]["scenes"]})) + "), rendered, not synthetic",
                "config": {"workload": wl["desc"], "mode": args.mode, "batch_paths": args.batch_paths,
                           "bvh": "built on the GPU (Morton order)" if args.device_bvh else "reference tree (host build)",
                           "paths_per_step": head["paths_per_step"],
-                          "sharding": ("spp range per rank (%s scaling), fp64 radiance reduce to rank 0" % args.scaling)
+                          "sharding": ("spp range per rank (%s scaling), fp64 radiance reduce to rank 0" % wl.get("scaling", args.scaling))
                                       if world > 1 else "single GPU",
                           "rccl_ranks": b.ranks_seen, "backend": b.backend if b.distributed else None},
                "roofline": head["roofline"], "workloads": extras, "fast_modes": fast}
+        if b.distributed:
+            out["render_ms"], out["reduce_ms"] = head["render_ms"], head["reduce_ms"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, also=[n for n in names if n == "dragon"])
         print(json.dumps(out), flush=True)

@@ -56,7 +56,11 @@ struct cpt_ctx {
     std::string err;
 
     void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_nodes32 = nullptr;
-    double scene_extent = 0.0;  // largest box-plane magnitude (of the root's two child boxes)
+    // Whether the tree on the device has the properties the binary32 extend variants rely on: every child box lies inside
+    // its parent's box and every leaf box is exactly the bounds of its triangle's vertices (then a leaf's box passing the
+    // exact test implies every box above it passes, and the root's two child boxes bound every plane of the tree).  The
+    // library's own trees have them by construction; an uploaded tree is checked.
+    bool tree_nested = false;
     // Triangles are kept on the device in an order of the library's own when the scene does not fit the extend kernel's
     // record cache whole (largest bounding box first: the cached prefix then holds the triangles most rays test);
     // tri_ext[internal] = the caller's index, tri_int the inverse.  Empty: the caller's order.
@@ -84,6 +88,8 @@ struct cpt_ctx {
     Lane lanes[CPT_MAX_LANES];
     int n_lanes = 2;
     hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_tail = nullptr;          // recorded on the context's stream after the latest asynchronous call
+    bool tail_recorded = false;
     unsigned long long* d_work = nullptr;  // paths, segments, hits, node steps, triangle tests
     unsigned char* d_static_scratch = nullptr;  // this GPU's copy of the file-scope `scratch` array (never freed)
 
@@ -121,6 +127,13 @@ static int fail(cpt_ctx* c, int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail((c), CPT_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// Leave a marker behind the asynchronous work a call has queued on the context's stream (see cpt_set_stream).
+static int mark_tail(cpt_ctx* c) {
+    HIP_TRY(c, hipEventRecord(c->ev_tail, c->stream));
+    c->tail_recorded = true;
+    return CPT_OK;
+}
+
 static void free_scene(cpt_ctx* c) {
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_tris) (void)hipFree(c->d_tris);
@@ -128,6 +141,8 @@ static void free_scene(cpt_ctx* c) {
     if (c->d_nodes32) (void)hipFree(c->d_nodes32);
     c->d_nodes = c->d_tris = c->d_shade = c->d_nodes32 = nullptr;
     c->has_scene = false;
+    c->tri_ext.clear();  // the index translation belongs to the scene that is gone
+    c->tri_int.clear();
 }
 static void free_paths(cpt_ctx::Lane& l) {
     if (l.d_paths) (void)hipFree(l.d_paths);
@@ -162,6 +177,7 @@ int cpt_create(int device, cpt_ctx** out) {
         if (e == hipSuccess && k > 0) e = hipStreamCreateWithFlags(&c->lanes[k].own_stream, hipStreamNonBlocking);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming);
     if (e == hipSuccess) e = static_scratch_for(device, &c->d_static_scratch);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_work, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->d_work, 0, 8 * sizeof(unsigned long long));
@@ -185,6 +201,7 @@ void cpt_destroy(cpt_ctx* c) {
         if (l.own_stream) (void)hipStreamDestroy(l.own_stream);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
     free_scene(c);
     if (c->d_work) (void)hipFree(c->d_work);
     for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
@@ -199,11 +216,15 @@ int cpt_set_stream(cpt_ctx* c, void* s) {
     hipStream_t next = s == CPT_OWN_STREAM ? c->own_stream : (hipStream_t)s;
     if (next == c->stream) return CPT_OK;
     // The context's buffers (lane 0's streams and counters, the scene arrays) are ordered by the stream they were
-    // last used on only: work queued on the new stream must not overtake what is still running on the old one.
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(next, c->ev_fork, 0));
+    // last used on only: work queued on the new stream must not overtake what is still running on the old one.  The
+    // new stream waits for the event the latest asynchronous call left behind; the old stream's handle is not
+    // touched (its owner may have destroyed it already), and the context moves to the new stream even when the
+    // wait could not be queued, so that it stays usable.
     c->stream = next;
+    if (c->tail_recorded) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamWaitEvent(next, c->ev_tail, 0));
+    }
     return CPT_OK;
 }
 
@@ -250,8 +271,11 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
 }
 
 // Whether the persistent extend kernel can run without any global-memory record or stack traffic.
-static bool variant_f32(const cpt_ctx* c) { return c->extend_variant >= 3; }
-static bool variant_cull(const cpt_ctx* c) { return c->extend_variant == 2 || c->extend_variant == 4; }
+// The binary32 test (3, 4) and the culling (2, 4) need a nested tree whose leaf boxes are their triangles' exact bounds: the first
+// so that a leaf's own box decides, the second so that no hit lies before the point where the ray enters a box above it or
+// the leaf's own.  On any other tree those variants run as variant 1, whose hits they would have returned.
+static bool variant_f32(const cpt_ctx* c) { return c->extend_variant >= 3 && c->tree_nested; }
+static bool variant_cull(const cpt_ctx* c) { return (c->extend_variant == 2 || c->extend_variant == 4) && c->tree_nested; }
 static int scene_resident(const cpt_ctx* c) {
     if (!c->has_scene || c->measured_height - 2 > CPT_PW_STACK_LDS_HOST) return 0;
     // 128-byte slots the scene takes in the record cache (binary32 node records are half a slot each)
@@ -285,6 +309,7 @@ static int validate_triangles(cpt_ctx* c, const cpt_scene_desc* s) {
 // largest take over 90 % of them).  Hit records, shading records and tie-break ranks use the internal index; the entry
 // points that report triangle indices translate back.
 struct OrderedScene {
+    std::vector<int32_t> tri_ext, tri_int;  // a freshly chosen order; moved into the context once the new scene is in place
     std::vector<cpt_tri> tris;
     std::vector<cpt_tri_normals> normals;
     std::vector<cpt_node> nodes;
@@ -299,29 +324,29 @@ static double box_area_of(const cpt_tri& t) {
 // description to use from here on, which points into `os` or is *s itself when the caller's order stands.
 static const cpt_scene_desc* order_scene(cpt_ctx* c, const cpt_scene_desc* s, bool new_order, bool with_nodes, OrderedScene& os) {
     const int n = s->n_tris;
-    if (new_order) {
-        c->tri_ext.clear();
-        c->tri_int.clear();
+    if (new_order) {  // into `os`: the context keeps the old scene's tables until the old scene is gone (commit_order)
         const long long n_nodes = with_nodes ? s->n_nodes : (long long)n - 1;
         if (n_nodes + n > CPT_PW_CACHE_RECORDS_HOST) {
             std::vector<double> area((size_t)n);
             for (int i = 0; i < n; ++i) area[(size_t)i] = box_area_of(s->tris[i]);
-            c->tri_ext.resize((size_t)n);
-            for (int i = 0; i < n; ++i) c->tri_ext[(size_t)i] = i;
-            std::stable_sort(c->tri_ext.begin(), c->tri_ext.end(), [&](int32_t a, int32_t b) {
+            os.tri_ext.resize((size_t)n);
+            for (int i = 0; i < n; ++i) os.tri_ext[(size_t)i] = i;
+            std::stable_sort(os.tri_ext.begin(), os.tri_ext.end(), [&](int32_t a, int32_t b) {
                 const double x = area[(size_t)a], y = area[(size_t)b];
                 return (x > y) || (x != x && y == y);  // NaN areas (non-finite vertices are refused elsewhere) first, deterministically
             });
-            c->tri_int.resize((size_t)n);
-            for (int i = 0; i < n; ++i) c->tri_int[(size_t)c->tri_ext[(size_t)i]] = i;
+            os.tri_int.resize((size_t)n);
+            for (int i = 0; i < n; ++i) os.tri_int[(size_t)os.tri_ext[(size_t)i]] = i;
         }
     }
-    if (c->tri_ext.empty() || (int)c->tri_ext.size() != n) return s;
+    const std::vector<int32_t>& ext = new_order ? os.tri_ext : c->tri_ext;
+    const std::vector<int32_t>& inv = new_order ? os.tri_int : c->tri_int;
+    if (ext.empty() || (int)ext.size() != n) return s;
     os.tris.resize((size_t)n);
     os.normals.resize((size_t)n);
     for (int i = 0; i < n; ++i) {
-        os.tris[(size_t)i] = s->tris[c->tri_ext[(size_t)i]];
-        os.normals[(size_t)i] = s->tri_normals[c->tri_ext[(size_t)i]];
+        os.tris[(size_t)i] = s->tris[ext[(size_t)i]];
+        os.normals[(size_t)i] = s->tri_normals[ext[(size_t)i]];
     }
     os.desc = *s;
     os.desc.tris = os.tris.data();
@@ -329,12 +354,45 @@ static const cpt_scene_desc* order_scene(cpt_ctx* c, const cpt_scene_desc* s, bo
     if (with_nodes && s->n_nodes > 0) {
         os.nodes.assign(s->nodes, s->nodes + s->n_nodes);
         for (cpt_node& nd : os.nodes) {
-            if (nd.lref < 0) nd.lref = ~c->tri_int[(size_t)(~nd.lref)];
-            if (nd.rref < 0) nd.rref = ~c->tri_int[(size_t)(~nd.rref)];
+            if (nd.lref < 0) nd.lref = ~inv[(size_t)(~nd.lref)];
+            if (nd.rref < 0) nd.rref = ~inv[(size_t)(~nd.rref)];
         }
         os.desc.nodes = os.nodes.data();
     }
     return &os.desc;
+}
+// The new scene's index translation takes effect together with the new scene (free_scene has cleared the old one's).
+static void commit_order(cpt_ctx* c, OrderedScene& os) {
+    c->tri_ext = std::move(os.tri_ext);
+    c->tri_int = std::move(os.tri_int);
+}
+
+// Whether every child box of the tree lies inside its parent's box and every leaf box equals the bounds of its
+// triangle's three vertices (see cpt_ctx::tree_nested).  The root has no box of its own.
+static bool tree_is_nested(const cpt_scene_desc* s) {
+    auto inside = [](const double* in, const double* out) {
+        for (int k = 0; k < 3; ++k)
+            if (!(in[k] >= out[k]) || !(in[k + 3] <= out[k + 3])) return false;
+        return true;
+    };
+    for (int k = 0; k < s->n_nodes; ++k) {
+        const cpt_node& nd = s->nodes[k];
+        const int refs[2] = {nd.lref, nd.rref};
+        const double* boxes[2] = {nd.lbox, nd.rbox};
+        for (int q = 0; q < 2; ++q) {
+            if (refs[q] >= 0) {
+                const cpt_node& ch = s->nodes[refs[q]];
+                if (!inside(ch.lbox, boxes[q]) || !inside(ch.rbox, boxes[q])) return false;
+            } else {
+                const cpt_tri& t = s->tris[~refs[q]];
+                for (int a = 0; a < 3; ++a) {
+                    const double lo = std::min(t.a[a], std::min(t.b[a], t.c[a])), hi = std::max(t.a[a], std::max(t.b[a], t.c[a]));
+                    if (boxes[q][a] != lo || boxes[q][a + 3] != hi) return false;
+                }
+            }
+        }
+    }
+    return true;
 }
 
 static int validate_scene(cpt_ctx* c, const cpt_scene_desc* s, int* measured_height) {
@@ -431,6 +489,7 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     int measured = 0;
     int rc = validate_scene(c, s, &measured);
     if (rc != CPT_OK) return rc;
+    const bool nested = tree_is_nested(s);  // references were validated above
     OrderedScene ordered;
     s = order_scene(c, s, true, true, ordered);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -475,6 +534,8 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     c->measured_height = measured;
     rc = make_nodes32(c, s->n_nodes);
     if (rc != CPT_OK) return rc;
+    commit_order(c, ordered);
+    c->tree_nested = nested;
     c->has_scene = true;
     return CPT_OK;
 }
@@ -532,6 +593,8 @@ int cpt_build_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     c->measured_height = height;
     rc = make_nodes32(c, n - 1);
     if (rc != CPT_OK) return rc;
+    commit_order(c, ordered);
+    c->tree_nested = true;  // the build's boxes are exact unions, leaf boxes exact bounds
     c->has_scene = true;
     return CPT_OK;
 }
@@ -589,6 +652,7 @@ int cpt_refit_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     rc = make_nodes32(c, m);  // the boxes changed
     if (rc != CPT_OK) return rc;
     c->sc.cam = s->camera;
+    c->tree_nested = true;  // every box is now the exact union of what lies below it
     return CPT_OK;
 }
 
@@ -651,7 +715,7 @@ static int ensure_spill(cpt_ctx* c, cpt_ctx::Lane& l, hipStream_t st) {
     HIP_TRY(c, hipStreamSynchronize(st));
     if (l.d_spill) (void)hipFree(l.d_spill);
     l.d_spill = nullptr;
-    HIP_TRY(c, hipMalloc((void**)&l.d_spill, (size_t)(CPT_PW_STACK_MAX - CPT_PW_STACK_LDS_LARGE_HOST) * (size_t)c->pw_blocks * CPT_PW_THREADS_HOST * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void**)&l.d_spill, (size_t)(CPT_PW_STACK_MAX - CPT_PW_STACK_LDS_HOST) * (size_t)c->pw_blocks * CPT_PW_THREADS_HOST * sizeof(uint32_t)));
     l.spill_blocks = c->pw_blocks;
     return CPT_OK;
 }
@@ -824,7 +888,7 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
         c->stats.launches_mega++;
         c->stats.paths += (uint64_t)n_paths;
         if (work) return collect_work(c);
-        return CPT_OK;
+        return mark_tail(c);
     }
 
     // wavefront: batches of whole samples, dealt to the lanes in turn
@@ -852,14 +916,14 @@ int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {
     if (rc) return rc;
     c->stats.paths += (uint64_t)n_paths;
     if (work) return collect_work(c);
-    return CPT_OK;
+    return mark_tail(c);
 }
 
 // Stack-spill columns the persistent extend kernel can touch on this context's scene: one per stack entry beyond
 // the LDS part, for every thread of every persistent workgroup.
 static size_t spill_bytes_needed(const cpt_ctx* c) {
     if (c->extend_variant < 1) return 0;
-    const int entries = std::max(c->measured_height, c->tree_height) - 2 - CPT_PW_STACK_LDS_LARGE_HOST;
+    const int entries = std::max(c->measured_height, c->tree_height) - 2 - CPT_PW_STACK_LDS_HOST;
     return entries > 0 ? (size_t)entries * (size_t)c->pw_blocks * CPT_PW_THREADS_HOST * sizeof(uint32_t) : 0;
 }
 
@@ -903,7 +967,7 @@ int cpt_render_noalloc(cpt_ctx* c, const cpt_render_params* p, double* d_accum) 
     rc = run_wavefront(c, P, launch_cfg(c), lanes, st, 1, batch, false, nullptr, d_accum);
     if (rc) return rc;
     c->stats.paths += (uint64_t)(window_pixels(P) * (P.s1 - P.s0));
-    return CPT_OK;
+    return mark_tail(c);
 }
 
 int cpt_tonemap(cpt_ctx* c, const double* d_accum, int32_t w, int32_t h, int32_t total_spp, uint8_t* d_rgb) {
@@ -915,7 +979,7 @@ int cpt_tonemap(cpt_ctx* c, const double* d_accum, int32_t w, int32_t h, int32_t
     LaunchCfg L = launch_cfg(c);
     launch_tonemap(L, d_accum, (long long)w * h * 3, total_spp, d_rgb);
     HIP_TRY(c, hipGetLastError());
-    return CPT_OK;
+    return mark_tail(c);
 }
 
 int cpt_render_image(cpt_ctx* c, const cpt_render_params* p, uint8_t* h_rgb) {

@@ -400,6 +400,14 @@ __device__ __forceinline__ double pow_negative_base(double y) {
     return (rint(y * 0.5) * 2.0 != y) ? -1.0 : 1.0;
 }
 
+// |kt|^t as exp(t * log|kt|), log|kt| given.  Where the product is NaN although neither factor is (t = 0 with
+// kt = 0, t infinite with |kt| = 1) pow's value is 1.
+__device__ __forceinline__ double kt_power(double t, double log_kt) {
+    const double e = t * log_kt;
+    const double v = exp(e);
+    return (e != e && (t == 0.0 || log_kt == 0.0)) ? 1.0 : v;
+}
+
 // Scatter with the chosen lobe: replace the ray, scale the throughput.
 // reference: src/path_tracer.cu:284-396.
 //
@@ -455,10 +463,13 @@ __device__ __forceinline__ void scatter(int lobe, const DScene& sc, const DParam
             // kt^t as exp(t log|kt|) with log|kt| from the shading record: a few ulp from pow (relative error
             // about |t log kt| ulp), a quarter of its instructions and none of its registers.  kt = 0 gives
             // exp(-inf) = 0 like pow; a negative kt follows pow's rule for a negative base (pow_negative_base).
+            // t is a hit distance (>= 0, finite on finite scenes); the two products that pow defines but the
+            // exponential form turns into NaN -- 0 * log 0 (pow(0, 0) = 1) and inf * log 1 (pow(1, inf) = 1) -- are put
+            // right by kt_power.
             const dvec3 lk = dv(m->log_kt);
-            tr.x = exp(t * lk.x);
-            tr.y = (kt.y == kt.x) ? tr.x : exp(t * lk.y);  // equal inputs give equal results: computed once
-            tr.z = (kt.z == kt.x) ? tr.x : ((kt.z == kt.y) ? tr.y : exp(t * lk.z));
+            tr.x = kt_power(t, lk.x);
+            tr.y = (kt.y == kt.x) ? tr.x : kt_power(t, lk.y);  // equal inputs give equal results: computed once
+            tr.z = (kt.z == kt.x) ? tr.x : ((kt.z == kt.y) ? tr.y : kt_power(t, lk.z));
             if (kt.x < 0 || kt.y < 0 || kt.z < 0) {
                 const double sign = pow_negative_base(t);
                 if (kt.x < 0) tr.x = sign * tr.x;

@@ -227,42 +227,21 @@ static_assert(CPT_PW_CACHE_RECORDS == CPT_PW_CACHE_RECORDS_HOST, "record cache s
 #ifndef CPT_PW_HOT_TRIS
 #define CPT_PW_HOT_TRIS 32    // record-cache slots kept for triangles when the node records alone would fill it
 #endif
-#ifndef CPT_PW_COOP
-#define CPT_PW_COOP 0         // 1: exact walk of scenes larger than the cache fetches missing node records wave-cooperatively
-#endif
-#ifndef CPT_PW_STAGE
-#define CPT_PW_STAGE 16       // staging slots per wave of the cooperative record fetch (a multiple of 8)
-#endif
-
-// How an instance of the persistent kernel divides the CU's 160 KB of LDS.
-//   RESIDENT (the scene lives in the cache whole) and F32: 64 KB of records, 12 node-stack entries and 10 parked
-//   leaves per lane.
-//   Exact walk of a larger scene (COOP): node records that are not cached are fetched by the wave as a whole, eight
-//   lanes per record, one full 128-byte line per record (see the box phase), into CPT_PW_STAGE slots per wave at the
-//   end of the cache planes.  The room comes from shorter LDS lists (8 + 8 entries per lane; deeper stack entries
-//   already go to global memory), and since no plane stores the never-read eighth piece of a record the planes hold
-//   more cached records than before on top of the staging slots.
+// How an instance of the persistent kernel divides the CU's 160 KB of LDS: 64 KB of scene records, 12 node-stack entries
+// and 10 parked leaves per lane (88 KB).  The exact variants keep the records as seven planes (planar_record), which
+// holds CPT_PW_PLANAR_SLOTS_HOST of them because the never-read eighth piece is not stored; the binary32 variants keep
+// CPT_PW_CACHE_RECORDS whole 128-byte slots (two 64-byte node records per slot).
 template <bool RESIDENT, bool F32>
 struct PwPlan {
-    static constexpr bool COOP = CPT_PW_COOP && !RESIDENT && !F32;
-    static constexpr int STACK_LDS = COOP ? CPT_PW_STACK_LDS_LARGE_HOST : CPT_PW_STACK_LDS_HOST;  // node-stack entries per lane in LDS
-    static constexpr int LEAF_CAP = COOP ? 8 : 10;   // parked leaves per lane (a node expansion adds at most two)
-    static constexpr int STAGE = COOP ? CPT_PW_STAGE : 0;
-    static constexpr int LIST_BYTES = CPT_PW_WAVES * (STACK_LDS + LEAF_CAP) * CPT_WAVE * 4 + (COOP ? CPT_PW_WAVES * CPT_PW_STAGE * 4 : 0);
-    // planar layouts: slots per plane, odd so that the eight pieces of one record fall into eight different bank groups
-    static constexpr int PLANE_SLOTS_RAW = COOP ? (160 * 1024 - 256 - LIST_BYTES) / 112 : CPT_PW_PLANAR_SLOTS_HOST;
-    static constexpr int PLANE_SLOTS = (PLANE_SLOTS_RAW & 1) ? PLANE_SLOTS_RAW : PLANE_SLOTS_RAW - 1;
+    static constexpr int STACK_LDS = CPT_PW_STACK_LDS_HOST;  // node-stack entries per lane in LDS
+    static constexpr int LEAF_CAP = 10;                      // parked leaves per lane (a node expansion adds at most two)
+    static constexpr int PLANE_SLOTS = CPT_PW_PLANAR_SLOTS_HOST;
     static constexpr int PLANE_BYTES = PLANE_SLOTS * 16;
-    static constexpr int CACHED_SLOTS = F32 ? CPT_PW_CACHE_RECORDS : PLANE_SLOTS - CPT_PW_WAVES * STAGE;  // record slots of the cache proper
-    static constexpr int STAGE_FIRST = CACHED_SLOTS;  // the staging slots follow the cached ones in every plane
-    static constexpr int CACHE_BYTES = COOP ? 7 * PLANE_BYTES : CPT_PW_CACHE_RECORDS * 128;
+    static constexpr int CACHED_SLOTS = F32 ? CPT_PW_CACHE_RECORDS : PLANE_SLOTS;  // record slots of the cache
+    static constexpr int CACHE_BYTES = CPT_PW_CACHE_RECORDS * 128;
     static_assert(7 * PLANE_BYTES <= CACHE_BYTES, "the seven planes must fit the cache");
-    static_assert(CACHE_BYTES + LIST_BYTES <= 160 * 1024, "LDS budget of one workgroup");
-    static_assert(STAGE % 8 == 0, "a load instruction stages eight records");
+    static_assert(PLANE_SLOTS & 1, "an odd number of slots per plane puts the pieces of one record into different bank groups");
 };
-static_assert(PwPlan<true, false>::STACK_LDS == CPT_PW_STACK_LDS_HOST && PwPlan<false, false>::STACK_LDS >= CPT_PW_STACK_LDS_LARGE_HOST,
-              "stack split must match the spill buffer sizing");
-static_assert(PwPlan<true, false>::CACHED_SLOTS == CPT_PW_PLANAR_SLOTS_HOST, "the host decides residency by this number");
 
 struct Rec7 {  // the first seven 16-byte pieces of a 128-byte record
     double2 p0, p1, p2, p3, p4, p5, p6;
@@ -456,13 +435,11 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                                                               uint32_t chunk, uint32_t refill_at, uint32_t leaf_go, uint32_t full_go, uint32_t* spill, unsigned long long* work,
                                                               ExtendObserve obs) {
     typedef PwPlan<RESIDENT, F32> Plan;
-    constexpr bool COOP = Plan::COOP;
     constexpr int kStackLds = Plan::STACK_LDS, kLeafCap = Plan::LEAF_CAP;
     constexpr int kPlaneBytes = F32 ? 0 : Plan::PLANE_BYTES;  // 0: whole records with rotated pieces (fetch_record)
     __shared__ __attribute__((aligned(128))) unsigned char s_cache[Plan::CACHE_BYTES];
     __shared__ uint32_t s_nodes[CPT_PW_WAVES][kStackLds][CPT_WAVE];
     __shared__ uint32_t s_leaves[CPT_PW_WAVES][kLeafCap][CPT_WAVE];
-    __shared__ uint32_t s_missing[COOP ? CPT_PW_WAVES * Plan::STAGE : 1];  // COOP: node indices of the records a wave is staging
     const uint32_t lane = threadIdx.x & (CPT_WAVE - 1), wave = threadIdx.x / CPT_WAVE;
     const uint64_t lanes_below = (1ull << lane) - 1ull;
     // lengths of the stream's segments, one per lane of every wave (lanes beyond the segments hold 0)
@@ -516,7 +493,6 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
         for (int k = 0; k < 12; ++k) m = fmax(m, fabs(b[k]));
         scene_extent = f32_up(m);
     }
-    if (COOP && threadIdx.x < CPT_PW_WAVES * Plan::STAGE) s_missing[threadIdx.x] = 0u;
     __syncthreads();
     const lds_byte* cache = (const lds_byte*)s_cache;
 
@@ -526,9 +502,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     lds_u32* const leaf_base = (lds_u32*)&s_leaves[wave][0][lane];  // entries are CPT_WAVE words apart
     lds_u32* leaf_top = leaf_base;
 #define CPT_LEAVES_AT_MOST(N) (leaf_top <= leaf_base + (N) * CPT_WAVE)
-    // COOP: this wave's staging slots in the cache planes and the list of node indices being staged
-    lds_u32* const missing = (lds_u32*)&s_missing[COOP ? wave * Plan::STAGE : 0];
-    const uint32_t stage_first = (uint32_t)Plan::STAGE_FIRST + wave * (uint32_t)Plan::STAGE;
+
     // likewise the node stack of the RESIDENT instances (the others count entries: theirs continues in global memory)
     lds_u32* const node_base = (lds_u32*)&s_nodes[wave][0][lane];
     lds_u32* node_top = node_base;
@@ -611,43 +585,6 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 uint64_t any_boxing = __ballot(boxing);
                 if (lane == 0 && any_boxing) box_passes++;
             }
-            // COOP: node records that are not in the cache are fetched by the wave as a whole.  A lane loading its own
-            // record issues seven 16-byte loads on a 128-byte line no other lane touches, so a pass with m such lanes
-            // costs the CU's one vector-memory address unit 7 m line look-ups (it was busy 65 % of the time on a
-            // 10 000-triangle scene, with the waves parked behind it).  Here the lanes that miss publish their node
-            // index in LDS, every group of eight lanes loads one of those records as one contiguous 128-byte line
-            // (lane p of the group its piece p) and writes it to the wave's staging slots at the end of the cache
-            // planes, and the lanes that missed then read their record from LDS like a cached one: m look-ups.
-            // A wave's LDS operations complete in order, so the hand-over needs no barrier.
-            uint32_t slot = (uint32_t)node;
-            bool direct = false;
-            if (COOP) {
-                const bool miss = boxing && node >= cached_nodes;
-                const uint64_t mm = __ballot(miss);
-                if (mm) {
-                    const uint32_t rank = (uint32_t)__popcll(mm & lanes_below), n_miss = (uint32_t)__popcll(mm);
-                    if (miss && rank < (uint32_t)Plan::STAGE) missing[rank] = (uint32_t)node;
-                    __builtin_amdgcn_wave_barrier();
-                    const uint32_t group = lane >> 3, piece = lane & 7u;
-                    if (piece < 7u) {
-                        v2d staged[Plan::STAGE / 8 > 0 ? Plan::STAGE / 8 : 1];
-#pragma unroll
-                        for (int k = 0; k < Plan::STAGE / 8; ++k) {
-                            const uint32_t j = group + 8u * k;
-                            const uint32_t idx = j < n_miss ? missing[j] : 0u;  // spare groups all read record 0: one line
-                            staged[k] = *(const v2d*)((const unsigned char*)sc.nodes + (size_t)idx * 128 + piece * 16u);
-                        }
-#pragma unroll
-                        for (int k = 0; k < Plan::STAGE / 8; ++k)
-                            *(lds_v2d*)((lds_byte*)s_cache + piece * (uint32_t)Plan::PLANE_BYTES + (stage_first + group + 8u * k) * 16u) = staged[k];
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (miss) {
-                        if (rank < (uint32_t)Plan::STAGE) slot = stage_first + rank;
-                        else direct = true;  // more misses than staging slots: these lanes fetch their own record
-                    }
-                }
-            }
             if (boxing) {
                 int2 refs;  // lref, rref
                 int2 ids;   // COUNT: canonical ids of the two children
@@ -664,9 +601,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                     enter_l = (double)el;
                     enter_r = (double)er;
                 } else {
-                    Rec7 r;
-                    if (COOP) r = direct ? global_record(sc.nodes, node) : planar_record<kPlaneBytes ? kPlaneBytes : 16>(cache, slot);
-                    else r = fetch_record<RESIDENT, kPlaneBytes>(sc.nodes, cache, 0, cached_nodes, node);
+                    const Rec7 r = fetch_record<RESIDENT, kPlaneBytes>(sc.nodes, cache, 0, cached_nodes, node);
                     refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));
                     ids = make_int2(__double2loint(r.p6.y), __double2hiint(r.p6.y));
                     bool sure_l, sure_r;

@@ -119,12 +119,8 @@ struct Radiance {           // radiance gathered per path, indexed by slot; touc
 };
 #define CPT_SLOT_BYTES (2 * CPT_STREAM_BYTES + 16 + 24)  // device bytes per path slot of a batch: two streams, hit record, radiance
 
-// traversal stack of the persistent-wave extend kernel: entries in LDS, and the deepest tree it accepts.  The instances
-// for scenes that live in the record cache whole keep CPT_PW_STACK_LDS_HOST entries per lane in LDS and have no spill
-// path; the instances for larger scenes keep CPT_PW_STACK_LDS_LARGE_HOST (their LDS also holds the staging slots of
-// the wave-cooperative record fetch) and continue in a per-lane column of global memory.
+// traversal stack of the persistent-wave extend kernel: entries in LDS, and the deepest tree it accepts
 #define CPT_PW_STACK_LDS_HOST 12
-#define CPT_PW_STACK_LDS_LARGE_HOST 8
 #define CPT_PW_STACK_MAX 62
 // The rays of a stream are handed to the persistent extend kernel's waves in small chunks.  One claim
 // counter for the whole stream would serialise the claims (an address takes on the order of 10^8

@@ -144,7 +144,11 @@ const char* cpt_last_error(const cpt_ctx* ctx);
 /* Launch on this hipStream_t (passed as void*) instead of the context's own stream.  As everywhere
  * in HIP, NULL is the legacy default stream; CPT_OWN_STREAM goes back to the context's own stream,
  * which is an ordinary (blocking) stream: it is ordered after work queued earlier on the legacy
- * default stream, so buffers prepared there can be handed to cpt_render without a fence. */
+ * default stream, so buffers prepared there can be handed to cpt_render without a fence.
+ * Work the context queued earlier (cpt_render, cpt_render_noalloc, cpt_tonemap) is ordered before what it queues
+ * on the new stream: the new stream is made to wait for an event those calls leave behind.  The previous stream's
+ * handle is not used by this call, so it may already have been destroyed; the context moves to the new stream even
+ * when the call returns an error (the wait could not be queued).  Not for use while either stream is being captured. */
 #define CPT_OWN_STREAM ((void*)-1)
 int cpt_set_stream(cpt_ctx* ctx, void* hip_stream);
 /* Tuning knobs, by name: "batch_paths" (path slots of one batch of the wavefront pipeline,
@@ -160,7 +164,11 @@ int cpt_set_stream(cpt_ctx* ctx, void* hip_stream);
  * conservative, and every candidate leaf is then put to the exact binary64 test of its own box before its triangle
  * is tested: because a box that contains a leaf's box can never fail the reference's test when the leaf's box
  * passes it, the closest hits are exactly those of variant 1, from a slightly larger visit set and a third less
- * arithmetic per node; 4: as 3 with the nearest-first walk and culling of 2),
+ * arithmetic per node; 4: as 3 with the nearest-first walk and culling of 2.  2, 3 and 4 rest on two properties of the
+ * tree: every child box lies inside its parent's box, and every leaf box is exactly the bounds of its triangle's
+ * three vertices.  Trees built or refitted by the library have them; cpt_upload_scene checks the caller's tree, and on
+ * a tree without them (padded or tightened leaf boxes, boxes that are not nested -- which the reference's walk, and
+ * so variants 0 and 1, take as they come) the context runs 2, 3 and 4 as 1),
  * "pw_blocks" / "pw_chunk" (workgroups of the persistent extend kernel / rays a wave claims per
  * atomic, 0 = chosen from the scene size),
  * "pw_refill" / "pw_leaf_go" / "pw_full_go" (a wave of that kernel refills when this many lanes are
@@ -212,7 +220,7 @@ int cpt_render(cpt_ctx* ctx, const cpt_render_params* params, double* d_accum);
  * library's device code, so the call makes no hipMalloc / hipFree and creates no events or streams.  It has no
  * counterpart in the reference (whose render path allocates per object, src/gpu/GPUManaged.cuh:19-24).
  * Limits: one sample of the tile window must fit, i.e.
- *   2 * 2 KB * (depth + 2)  +  4 KB * CUs * max(0, tree height - 10)  +  208 B * (pixels of the window, in whole 8x8 tiles)
+ *   2 * 2 KB * (depth + 2)  +  4 KB * CUs * max(0, tree height - 14)  +  208 B * (pixels of the window, in whole 8x8 tiles)
  * must not exceed CPT_NOALLOC_SCRATCH_BYTES (a 512x512 image at any accepted tree height does; a 1024x1024 image is
  * rendered as four tile windows); otherwise CPT_ELIMIT.  Samples are rendered in as large batches as fit, one batch
  * at a time on the context's stream; instrumentation settings are ignored.  Every context on a GPU shares that

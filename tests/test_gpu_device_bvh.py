@@ -269,6 +269,58 @@ def test_tall_morton_chain_is_rebuilt_with_coarser_codes(gpu, oracle, tmp_path):
     compare_with_oracle_on_same_tree(gpu, orc, boxes, 3000, 6)
 
 
+def test_uploaded_tree_without_nested_boxes_runs_the_binary32_variants_as_exact_ones(gpu, host_scenes, oracle):
+    """Extend variants 3 and 4 return variant 1's hits only on a tree whose child boxes lie inside their parents'
+    boxes and whose leaf boxes are exactly their triangles' bounds.  A caller's tree with tightened leaf boxes (here:
+    every leaf box shrunk to its lower half along x, so rays that pierce only the other half must miss the triangle)
+    is valid for the reference's walk; the library accepts it, notices that the binary32 variants' assumptions do
+    not hold (nor the culling variants': a hit may lie before the point where the ray enters the tightened box), and
+    runs all of them as the reference walk: hits, distances and the very same node and triangle counts as the oracle
+    walking that tree."""
+    import ctypes as C
+    from cuda_path_tracer_amd import _capi
+    hs = host_scenes("teapot-trans")
+    nodes = hs.nodes().copy()
+    for side, ref in (("lbox", "lref"), ("rbox", "rref")):
+        leaf = nodes[ref] < 0
+        mid = 0.5 * (nodes[side][leaf, 0] + nodes[side][leaf, 3])
+        b = nodes[side][leaf]
+        b[:, 3] = mid
+        nodes[side][leaf] = b
+
+    class Shim:
+        pass
+    sh = Shim()
+    sh.keep = np.ascontiguousarray(nodes)
+    sh.desc = _capi.SceneDesc()
+    C.memmove(C.byref(sh.desc), C.byref(hs.desc), C.sizeof(sh.desc))
+    sh.desc.nodes = C.cast(sh.keep.ctypes.data, C.POINTER(_capi.Node))
+    sh.n_tree_nodes = hs.n_tree_nodes
+    gpu.upload(sh)
+    boxes, topo = tree_table(nodes, hs.n_tris)
+    orc = oracle.OracleScene(scene_path("teapot-trans"))
+    orc.set_tree(boxes, topo)
+    rng = np.random.default_rng(31)
+    o, d = random_rays(boxes, rng, 20000)
+    want = orc.trace(o, d)
+    whole = oracle.OracleScene(scene_path("teapot-trans")).trace(o, d)
+    assert (want["prim"] != whole["prim"]).sum() > 50, "the tightened boxes should change some hits"
+    try:
+        for variant in (1, 3, 4, 2):
+            gpu.set_option("extend_variant", variant)
+            gpu.reset_stats()
+            gpu.set_instrumentation(False, True)
+            tri, t = gpu.extend_rays(o, d)
+            st = gpu.stats()
+            assert np.array_equal(tri, want["prim"]) and np.array_equal(bits(t), bits(want["t"])), "variant %d" % variant
+            if True:  # every variant has fallen back to the reference walk
+                assert st["node_steps"] == int(want["node_steps"].sum()) and st["tri_tests"] == int(want["tri_tests"].sum())
+    finally:
+        gpu.set_option("extend_variant", 1)
+        gpu.set_instrumentation(False, False)
+        gpu.reset_stats()
+
+
 def test_cli_with_device_built_tree(tmp_path, gpu, host_scenes):
     """bin/ray -g --device-bvh skips the host build and writes the image the library renders on its own tree."""
     import os

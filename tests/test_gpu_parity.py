@@ -721,6 +721,39 @@ def test_bench_two_ranks_on_one_gpu(scaling, launcher):
     assert 0 < out["roofline"]["frac"] <= 1 and out["roofline"]["bound"] == "fp64_valu_issue"
 
 
+def test_bench_full_node_shapes_on_two_ranks():
+    """The line bench.py prints for N > 1: beside the weak-scaling headline, the fixed-total shapes of the full-node
+    configurations (here at 1/8 of their width and 1/64 of their samples) dealt over the ranks, each with the slowest
+    rank's render and reduce times and the number of ranks the reduce went through."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, CPT_BENCH_BACKEND="gloo", CPT_BENCH_SHRINK="8")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", "cornell2",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["paths_per_step"] == 2 * 512 * 512 * 16
+    assert out["render_ms"] > 0 and out["reduce_ms"] >= 0
+    assert "synthetic" not in out["data"].split(",")[0] and "cornell-box2" in out["data"]
+    want = {"cfg4": 128 * 128 * 64, "cfg5_cornell": 64 * 64 * 256, "cfg5_dragon": 256 * 256 * 128}
+    assert set(out["workloads"]) == set(want)
+    for name, paths in want.items():
+        w = out["workloads"][name]
+        assert w["scaling"] == "strong" and w["n_gpus"] == 2 and w["rccl_ranks"] == 2
+        assert w["paths_per_step"] == paths and w["value"] > 0
+        assert w["render_ms"] > 0 and w["reduce_ms"] >= 0
+    rf = out["roofline"]
+    assert rf["instr_per_node_step"] == 70 and rf["instr_per_triangle_test"] == 89
+    assert rf["hbm_algorithmic_ratio_to_hbm_peak"] > 0
+
+
 def test_bench_one_rank_through_rccl():
     """What one GPU can rehearse of the RCCL path: bench.py under the launcher with a single rank and
     CPT_BENCH_FORCE_DIST=1 brings the nccl (= RCCL) process group up on the device and sends the warm-up reduce, every
@@ -798,6 +831,35 @@ def test_deep_stacks_spill_past_the_lds_entries(tmp_path, gpu, oracle):
             assert np.array_equal(tri, want["prim"]) and np.array_equal(bits(t), bits(want["t"])), variant
     finally:
         gpu.set_option("extend_variant", 1)
+
+
+def test_stream_handover_does_not_touch_the_previous_stream(gpu_scene):
+    """cpt_set_stream orders the new stream behind the context's earlier work through an event of the context's own,
+    not through the previous stream's handle: the previous stream may be gone by then (a torch stream that went out
+    of scope).  Renders on three streams in a row, each handed over after the one before was dropped, add up to the
+    one-stream render bit for bit."""
+    import gc
+    import torch
+    g = gpu_scene("cornell-box2-specular")
+    w, h, depth = 96, 96, 5
+    want = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+    g.set_stream(None)
+    g.render_into(want.data_ptr(), g.params(w, h, 0, 9, depth))
+    g.synchronize()
+    got = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    try:
+        for k in range(3):
+            st = torch.cuda.Stream()
+            g.set_stream(st.cuda_stream)
+            g.render_into(got.data_ptr(), g.params(w, h, 3 * k, 3 * k + 3, depth))
+            del st
+            gc.collect()
+    finally:
+        g.set_stream(None)
+    g.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(want.view(torch.int64), got.view(torch.int64))
 
 
 def test_malformed_scenes_are_refused_at_upload(gpu, host_scenes):
