@@ -234,9 +234,10 @@ class Bench:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
-    def measure(self, key, steps, warmup, with_roofline=True, options=()):
+    def measure(self, key, steps, warmup, with_roofline=True, options=(), tree=None):
         """Time `steps` steps of workload `key` after `warmup` untimed ones; returns the record (rank 0) or None.
-        `options`: (key, value) pairs for cpt_set_option on top of the command line's."""
+        `options`: (key, value) pairs for cpt_set_option on top of the command line's; `tree`: "reference" or "fast"
+        (the command line's choice when None)."""
         torch, dist, args = self.torch, self.dist, self.args
         from cuda_path_tracer_amd import MODE_MEGAKERNEL, MODE_WAVEFRONT, HostScene, Renderer
         from cuda_path_tracer_amd.dist import reduce_radiance, shard
@@ -259,6 +260,8 @@ class Bench:
                 r.set_option(k, int(v))
             if args.device_bvh:
                 r.build(hs)
+            elif (tree or args.tree) == "fast":
+                r.upload(hs.fast())
             else:
                 r.upload(hs)
             w = wl["width"]
@@ -440,6 +443,10 @@ def main():
     ap.add_argument("--device-bvh", action="store_true",
                     help="have the GPU build the BVH (a Morton-order tree) instead of uploading the reference's tree; "
                          "same image up to ties, different visit sets, so not the parity configuration")
+    ap.add_argument("--tree", default="reference", choices=["reference", "fast"],
+                    help="reference: the reference's BVH, which makes every ray test exactly the boxes the reference tests (the parity "
+                         "configuration); fast: the host library's surface-area tree over the same triangles with the reference's "
+                         "tie-break ranks -- same hits, same image bit for bit, about a third fewer box tests")
     ap.add_argument("--opt", action="append", default=[], help="key=value passed to cpt_set_option (tuning experiments)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -468,8 +475,10 @@ def main():
     if not args.no_fast_modes and args.mode == "wavefront" and b.world == 1:
         for name in [args.workload] + names:
             rec = {}
-            for label, variant in (("binary32_inner_nodes", 3), ("binary32_inner_nodes_and_culling", 4)):
-                r = b.measure(name, 2, 1, with_roofline=False, options=(("extend_variant", variant),))
+            for label, variant, tree in (("binary32_inner_nodes", 3, None), ("binary32_inner_nodes_and_culling", 4, None),
+                                         ("surface_area_tree", 1, "fast"), ("surface_area_tree_and_culling", 2, "fast"),
+                                         ("surface_area_tree_binary32_inner_nodes_and_culling", 4, "fast")):
+                r = b.measure(name, 2, 1, with_roofline=False, options=(("extend_variant", variant),), tree=tree)
                 if r is not None:
                     rec[label] = {"value": r["value"], "unit": "Mpaths/s", "ms_per_step": r["ms_per_step"]}
             if b.rank == 0:
@@ -485,7 +494,8 @@ def main():
                "data": "the reference's bundled scenes (tests/golden/scenes/*.ray: " + ", ".join(
                    sorted({n for k in [args.workload] + names for n in WORKLOADS[k]["scenes"]})) + "), rendered, not synthetic",
                "config": {"workload": wl["desc"], "mode": args.mode, "batch_paths": args.batch_paths,
-                          "bvh": "built on the GPU (Morton order)" if args.device_bvh else "reference tree (host build)",
+                          "bvh": "built on the GPU (Morton order)" if args.device_bvh else
+                                 ("surface-area tree (host build), reference tie-break ranks" if args.tree == "fast" else "reference tree (host build)"),
                           "paths_per_step": head["paths_per_step"],
                           "sharding": ("spp range per rank (%s scaling), fp64 radiance reduce to rank 0" % wl.get("scaling", args.scaling))
                                       if world > 1 else "single GPU",

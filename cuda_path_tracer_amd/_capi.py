@@ -48,7 +48,7 @@ class Camera(C.Structure):
 
 class SceneDesc(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("n_tris", C.c_int32), ("n_materials", C.c_int32),
-                ("n_tree_nodes", C.c_int32), ("tree_height", C.c_int32), ("pad_", C.c_int32),
+                ("n_tree_nodes", C.c_int32), ("tree_height", C.c_int32), ("flags", C.c_uint32),
                 ("nodes", C.POINTER(Node)), ("tris", C.POINTER(Tri)), ("tri_normals", C.POINTER(TriNormals)),
                 ("materials", C.POINTER(Material)), ("camera", Camera)]
 
@@ -86,7 +86,7 @@ AMD_SYMBOLS = [
 # every symbol include/cpt_host.h declares
 HOST_SYMBOLS = [
     "cpth_load", "cpth_load_text", "cpth_free", "cpth_describe", "cpth_aspect", "cpth_warning_count", "cpth_warning",
-    "cpth_tree_nodes", "cpth_write_image",
+    "cpth_tree_nodes", "cpth_write_image", "cpth_describe_fast", "cpth_fast_tree_nodes",
 ]
 
 _amd = None
@@ -145,6 +145,8 @@ def host():
         L.cpth_free.argtypes = [vp]
         L.cpth_free.restype = None
         L.cpth_describe.argtypes = [vp, C.POINTER(SceneDesc)]
+        L.cpth_describe_fast.argtypes = [vp, C.POINTER(SceneDesc)]
+        L.cpth_fast_tree_nodes.argtypes = [vp, vp, vp]
         L.cpth_aspect.argtypes = [vp]
         L.cpth_aspect.restype = C.c_double
         L.cpth_warning_count.argtypes = [vp]

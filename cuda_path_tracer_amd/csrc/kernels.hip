@@ -215,14 +215,14 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
 // Queue entries are claimed in chunks: one atomic per `chunk` rays, the rest is wave-local.
 // The per-lane node stack keeps its first entries in LDS (PwPlan::STACK_LDS); deeper entries (rare)
 // go to a per-lane column of `spill` in global memory.
-#ifndef CPT_PW_THREADS
-#define CPT_PW_THREADS 1024
-#endif
+#define CPT_PW_THREADS CPT_PW_THREADS_HOST
 #define CPT_PW_WAVES (CPT_PW_THREADS / CPT_WAVE)
-#define CPT_PW_CACHE_RECORDS 512  // 64 KB of 128-byte records
-static_assert(CPT_PW_CACHE_RECORDS == CPT_PW_CACHE_RECORDS_HOST, "record cache size must match the host's chunk choice");
+#define CPT_PW_CACHE_RECORDS CPT_PW_CACHE_RECORDS_HOST  // 64 KB of 128-byte records
 #ifndef CPT_PW_BOX_REPEAT
 #define CPT_PW_BOX_REPEAT 3   // node expansions per lane and loop turn
+#endif
+#ifndef CPT_PW_LEAF_CAP
+#define CPT_PW_LEAF_CAP 10
 #endif
 #ifndef CPT_PW_HOT_TRIS
 #define CPT_PW_HOT_TRIS 32    // record-cache slots kept for triangles when the node records alone would fill it
@@ -234,7 +234,7 @@ static_assert(CPT_PW_CACHE_RECORDS == CPT_PW_CACHE_RECORDS_HOST, "record cache s
 template <bool RESIDENT, bool F32>
 struct PwPlan {
     static constexpr int STACK_LDS = CPT_PW_STACK_LDS_HOST;  // node-stack entries per lane in LDS
-    static constexpr int LEAF_CAP = 10;                      // parked leaves per lane (a node expansion adds at most two)
+    static constexpr int LEAF_CAP = CPT_PW_LEAF_CAP;         // parked leaves per lane (a node expansion adds at most two)
     static constexpr int PLANE_SLOTS = CPT_PW_PLANAR_SLOTS_HOST;
     static constexpr int PLANE_BYTES = PLANE_SLOTS * 16;
     static constexpr int CACHED_SLOTS = F32 ? CPT_PW_CACHE_RECORDS : PLANE_SLOTS;  // record slots of the cache

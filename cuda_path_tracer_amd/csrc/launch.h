@@ -120,7 +120,9 @@ struct Radiance {           // radiance gathered per path, indexed by slot; touc
 #define CPT_SLOT_BYTES (2 * CPT_STREAM_BYTES + 16 + 24)  // device bytes per path slot of a batch: two streams, hit record, radiance
 
 // traversal stack of the persistent-wave extend kernel: entries in LDS, and the deepest tree it accepts
+#ifndef CPT_PW_STACK_LDS_HOST
 #define CPT_PW_STACK_LDS_HOST 12
+#endif
 #define CPT_PW_STACK_MAX 62
 // The rays of a stream are handed to the persistent extend kernel's waves in small chunks.  One claim
 // counter for the whole stream would serialise the claims (an address takes on the order of 10^8
@@ -132,9 +134,15 @@ struct Radiance {           // radiance gathered per path, indexed by slot; touc
 // Positions a stream of n rays needs, and the capacity of one of its CPT_PW_SEGMENTS segments.
 inline uint32_t cpt_segment_cap(size_t n) { return (uint32_t)(((n + CPT_PW_SEGMENTS - 1) / CPT_PW_SEGMENTS + 63) / 64 * 64); }
 inline size_t cpt_stream_positions(size_t n) { return (size_t)cpt_segment_cap(n) * CPT_PW_SEGMENTS; }
+#ifndef CPT_PW_CACHE_RECORDS_HOST
 #define CPT_PW_CACHE_RECORDS_HOST 512  // 128-byte records of the scene the persistent extend kernel keeps in LDS (its 64 KB record cache) ...
-#define CPT_PW_PLANAR_SLOTS_HOST 585   // ... and how many the exact variants keep, which store only the seven 16-byte pieces of a record that are ever read
+#endif
+// ... and how many the exact variants keep, which store only the seven 16-byte pieces of a record that are ever read
+// (585 for 64 KB; kept odd, see planar_record)
+#define CPT_PW_PLANAR_SLOTS_HOST (((CPT_PW_CACHE_RECORDS_HOST * 128 / 112) & 1) ? (CPT_PW_CACHE_RECORDS_HOST * 128 / 112) : (CPT_PW_CACHE_RECORDS_HOST * 128 / 112) - 1)
+#ifndef CPT_PW_THREADS_HOST
 #define CPT_PW_THREADS_HOST 1024
+#endif
 
 // What the counting instances of the extend kernels can report per ray besides the hit (all nullable; indexed by
 // stream position): the order-free hash of the canonical ids of every node whose box was tested, and one bitmap row

@@ -52,6 +52,20 @@ void emit_records(const Bvh& bvh, std::vector<cpt_node>& out) {
 
 }  // namespace
 
+cpt_scene_desc FlatScene::describe_fast() {
+    if (fast_bvh.nodes.empty() && !bounds.empty()) {
+        fast_bvh = build_bvh_sah(bounds);
+        emit_records(fast_bvh, fast_nodes);
+    }
+    cpt_scene_desc d = describe();
+    d.n_nodes = (int)fast_nodes.size();
+    d.n_tree_nodes = (int)fast_bvh.nodes.size();
+    d.tree_height = fast_bvh.height;
+    d.nodes = fast_nodes.data();
+    d.flags = CPT_SCENE_KEEP_RANKS;
+    return d;
+}
+
 cpt_scene_desc FlatScene::describe() const {
     cpt_scene_desc d;
     std::memset(&d, 0, sizeof d);
@@ -113,6 +127,11 @@ FlatScene flatten_scene(const RayScene& scene, bool build_tree) {
     if (build_tree) {
         f.bvh = build_bvh(bounds);
         emit_records(f.bvh, f.nodes);
+        // what cpt_upload_scene derives from these records anyway; filled in here so that the same triangle records can
+        // go with another tree (describe_fast) and still break ties the reference's way
+        const std::vector<uint32_t> rank = test_ranks(f.bvh, f.tris.size());
+        for (size_t i = 0; i < f.tris.size(); ++i) f.tris[i].test_rank = rank[i];
+        f.bounds = std::move(bounds);
     }
     return f;
 }

@@ -23,8 +23,14 @@ struct FlatScene {
     double aspect = 1.0;
     Bvh bvh;  // canonical tree, kept for inspection and tests
     std::vector<std::string> warnings;
+    // The fast mode's tree over the same triangles (build_bvh_sah), built on first use.  The triangle records carry
+    // the reference tree's tie-break ranks, so a walk of either tree returns the same hit for every ray.
+    std::vector<PrimBounds> bounds;
+    Bvh fast_bvh;
+    std::vector<cpt_node> fast_nodes;
 
     cpt_scene_desc describe() const;
+    cpt_scene_desc describe_fast();
 };
 
 // build_tree = false leaves `bvh` and `nodes` empty, for callers that have the GPU build the tree (cpt_build_scene).

@@ -53,6 +53,17 @@ int cpth_describe(const cpth_scene* s, cpt_scene_desc* out) {
     return 0;
 }
 
+int cpth_describe_fast(cpth_scene* s, cpt_scene_desc* out) {
+    if (!s || !out) return -1;
+    if (s->flat.bounds.empty()) return -1;  // loaded without a tree
+    try {
+        *out = s->flat.describe_fast();
+    } catch (const std::exception&) {
+        return -1;
+    }
+    return 0;
+}
+
 double cpth_aspect(const cpth_scene* s) { return s ? s->flat.aspect : 1.0; }
 int cpth_warning_count(const cpth_scene* s) { return s ? (int)s->flat.warnings.size() : 0; }
 const char* cpth_warning(const cpth_scene* s, int k) {
@@ -60,9 +71,18 @@ const char* cpth_warning(const cpth_scene* s, int k) {
     return s->flat.warnings[(size_t)k].c_str();
 }
 
+static int tree_table(const std::vector<cpt::BvhNode>& nodes, double* boxes, int32_t* topo);
 int cpth_tree_nodes(const cpth_scene* s, double* boxes, int32_t* topo) {
     if (!s || !boxes || !topo) return -1;
-    const auto& nodes = s->flat.bvh.nodes;
+    return tree_table(s->flat.bvh.nodes, boxes, topo);
+}
+int cpth_fast_tree_nodes(cpth_scene* s, double* boxes, int32_t* topo) {
+    if (!s || !boxes || !topo) return -1;
+    cpt_scene_desc d;
+    if (cpth_describe_fast(s, &d) != 0) return -1;
+    return tree_table(s->flat.fast_bvh.nodes, boxes, topo);
+}
+static int tree_table(const std::vector<cpt::BvhNode>& nodes, double* boxes, int32_t* topo) {
     for (size_t i = 0; i < nodes.size(); ++i) {
         boxes[6 * i] = nodes[i].lo.x; boxes[6 * i + 1] = nodes[i].lo.y; boxes[6 * i + 2] = nodes[i].lo.z;
         boxes[6 * i + 3] = nodes[i].hi.x; boxes[6 * i + 4] = nodes[i].hi.y; boxes[6 * i + 5] = nodes[i].hi.z;

@@ -55,6 +55,8 @@ void usage(const char* prog, const Cli& c) {
               << "  --batch <#>  path slots per batch (208 bytes each, two batches in flight; default 2^25, at most 2^28)\n"
               << "  --devices <#,#,...>  split the samples over these GPUs (one host thread and context each)\n"
               << "  --device-bvh        build the BVH on the GPU (a Morton-order tree, not the reference's)\n"
+              << "  --fast              fast mode: surface-area tree with the reference's tie-break ranks (same image, bit for bit,\n"
+              << "                      from about a third fewer box tests), nearest-first culling walk on large scenes\n"
               << "  --progressive <#>   rewrite the output image every # samples per pixel\n"
               << "  --checkpoint <FILE> resume from FILE if it matches this render, and save the radiance sums to it\n"
               << "  --metrics <FILE>    write timing and work counters as JSON\n";
@@ -84,7 +86,7 @@ int main(int argc, char** argv) {
                                 {"device", required_argument, nullptr, 1004}, {"progressive", required_argument, nullptr, 1005},
                                 {"checkpoint", required_argument, nullptr, 1006}, {"metrics", required_argument, nullptr, 1007},
                                 {"device-bvh", no_argument, nullptr, 1008},     {"devices", required_argument, nullptr, 1009},
-                                {"batch", required_argument, nullptr, 1010},
+                                {"batch", required_argument, nullptr, 1010},    {"fast", no_argument, nullptr, 1011},
                                 {nullptr, 0, nullptr, 0}};
     int o;
     while ((o = getopt_long(argc, argv, "tr:w:hj:c:gs:", longopts, nullptr)) != -1) {
@@ -114,6 +116,7 @@ int main(int argc, char** argv) {
             case 1007: c.metrics = optarg; break;
             case 1008: c.pt.device_bvh = true; break;
             case 1010: c.pt.batch_paths = atoll(optarg); break;
+            case 1011: c.pt.fast = true; break;
             case 1009:
                 c.pt.devices.clear();
                 for (const char* q = optarg; *q;) {

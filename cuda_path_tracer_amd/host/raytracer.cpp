@@ -73,6 +73,17 @@ static uint64_t scene_digest(const FlatScene& s) {
     return h;
 }
 
+cpt_scene_desc RayTracer::sceneDesc() {
+    const bool has_host_tree = !scene_->nodes.empty();
+    return (options.fast && has_host_tree) ? scene_->describe_fast() : scene_->describe();
+}
+// Culling pays on scenes whose rays could otherwise walk into many boxes behind their closest hit; on the small
+// bundled scenes (closed rooms of a few hundred triangles) the plain walk of the better tree is the faster one.
+bool RayTracer::applyWalkOptions(cpt_ctx* c) {
+    if (!options.fast) return true;
+    return cpt_set_option(c, "extend_variant", scene_->tris.size() > 2048 ? 2 : 1) == CPT_OK;
+}
+
 void RayTracer::traceImageGPU(int w, int h) { renderGPU(w, h, CPT_MODE_MEGAKERNEL); }
 void RayTracer::betterPathTracing(int w, int h) { renderGPU(w, h, CPT_MODE_WAVEFRONT); }
 
@@ -89,7 +100,8 @@ void RayTracer::renderGPU(int w, int h, int mode) {
         if (options.batch_paths > 0 && cpt_set_option(ctx_, "batch_paths", options.batch_paths) != CPT_OK) { error_ = cpt_last_error(ctx_); return; }
     }
     if (!uploaded_) {
-        cpt_scene_desc d = scene_->describe();
+        cpt_scene_desc d = sceneDesc();
+        if (!applyWalkOptions(ctx_)) { error_ = cpt_last_error(ctx_); return; }
         const bool on_device = scene_->nodes.empty() && scene_->tris.size() > 1;  // loaded without a host tree
         if ((on_device ? cpt_build_scene(ctx_, &d) : cpt_upload_scene(ctx_, &d)) != CPT_OK) { error_ = cpt_last_error(ctx_); return; }
         uploaded_ = true;
@@ -186,7 +198,7 @@ void RayTracer::renderGPU(int w, int h, int mode) {
 void RayTracer::renderMultiGPU(int w, int h, const cpt_render_params& p) {
     const size_t n = options.devices.size();
     more_ctx_.resize(n - 1, nullptr);
-    const cpt_scene_desc d = scene_->describe();
+    const cpt_scene_desc d = sceneDesc();
     const bool on_device = scene_->nodes.empty() && scene_->tris.size() > 1;
     std::vector<std::vector<double>> sums(n, std::vector<double>((size_t)w * h * 3, 0.0));
     std::vector<std::string> errors(n);
@@ -195,6 +207,7 @@ void RayTracer::renderMultiGPU(int w, int h, const cpt_render_params& p) {
         cpt_ctx*& c = k == 0 ? ctx_ : more_ctx_[k - 1];
         if (!c && cpt_create(options.devices[k], &c) != CPT_OK) { errors[k] = cpt_last_error(nullptr); c = nullptr; return; }
         if (k > 0 && options.batch_paths > 0 && cpt_set_option(c, "batch_paths", options.batch_paths) != CPT_OK) { errors[k] = cpt_last_error(c); return; }
+        if (k > 0 && !applyWalkOptions(c)) { errors[k] = cpt_last_error(c); return; }
         if (k > 0 && (on_device ? cpt_build_scene(c, &d) : cpt_upload_scene(c, &d)) != CPT_OK) { errors[k] = cpt_last_error(c); return; }
         const int total = p.sample_end - p.sample_begin, base = total / (int)n, extra = total % (int)n;
         cpt_render_params q = p;

@@ -24,6 +24,9 @@ struct PathTracingOptions {  // what the reference hard-codes in traceImageGPU (
     std::vector<int> devices;       // two or more GPU ordinals: samples are split across them (one host thread and one
                                     // context each), sums added on the host in list order; empty: `device` alone
     // long renders (no counterpart in the reference)
+    bool fast = false;              // the fast mode: the host library's surface-area tree (same triangles, the reference
+                                    // tree's tie-break ranks, so the same hits and the same image bit for bit) and, for
+                                    // scenes of more than 2048 triangles, the nearest-first walk with culling
     bool device_bvh = false;        // build the BVH on the GPU (cpt_build_scene) instead of on the host; set before loadScene
     int progressive_spp = 0;        // > 0: refresh the image every this many samples and call on_progress
     std::string checkpoint;         // non-empty: resume from this file if it matches, and save the sums to it
@@ -56,6 +59,8 @@ public:
 private:
     void renderGPU(int w, int h, int mode);
     void renderMultiGPU(int w, int h, const cpt_render_params& p);
+    cpt_scene_desc sceneDesc();            // the scene over the tree the options ask for
+    bool applyWalkOptions(cpt_ctx* c);     // the extend variant that goes with it
     std::unique_ptr<FlatScene> scene_;
     cpt_ctx* ctx_ = nullptr;
     std::vector<cpt_ctx*> more_ctx_;  // contexts of options.devices[1..]

@@ -46,6 +46,28 @@ class HostScene:
         except Exception:
             pass
 
+    def fast(self):
+        """The same scene over the fast mode's tree (full-sweep surface-area build; the triangle records keep the
+        reference tree's tie-break ranks, so every ray's closest hit is unchanged): an object Renderer.upload takes."""
+        if getattr(self, "_fast", None) is None:
+            f = FastTreeScene()
+            f.desc = _capi.SceneDesc()
+            if _capi.host().cpth_describe_fast(self._h, C.byref(f.desc)) != 0:
+                raise RuntimeError("the fast tree could not be built")
+            f.parent = self  # keeps the arrays alive
+            f.aspect = self.aspect
+            self._fast = f
+        return self._fast
+
+    def fast_tree(self):
+        """tree() of the fast mode's tree."""
+        f = self.fast()
+        n = f.n_tree_nodes
+        boxes = np.zeros((n, 6), np.float64)
+        topo = np.zeros((n, 3), np.int32)
+        _capi.host().cpth_fast_tree_nodes(self._h, boxes.ctypes.data_as(C.c_void_p), topo.ctypes.data_as(C.c_void_p))
+        return boxes, topo
+
     def height_for_width(self, width):
         """reference: src/ui/CommandLineUI.cpp:86"""
         return int(width / self.aspect + 0.5)
@@ -86,6 +108,17 @@ class HostScene:
     def camera(self):
         c = self.desc.camera
         return np.array(list(c.eye) + list(c.look) + list(c.u) + list(c.v), np.float64)
+
+
+class FastTreeScene:
+    """HostScene.fast(): the description of the same scene over the fast mode's tree."""
+    n_tris = property(lambda s: s.desc.n_tris)
+    n_nodes = property(lambda s: s.desc.n_nodes)
+    n_tree_nodes = property(lambda s: s.desc.n_tree_nodes)
+    tree_height = property(lambda s: s.desc.tree_height)
+
+    def height_for_width(self, width):
+        return self.parent.height_for_width(width)
 
 
 def write_image(path, rgb_bottom_up):

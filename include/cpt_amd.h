@@ -92,13 +92,17 @@ typedef struct cpt_scene_desc {
     int32_t n_materials;
     int32_t n_tree_nodes;            /* canonical node count (2*n_tris - 1)               */
     int32_t tree_height;             /* levels, root = 1                                   */
-    int32_t pad_;
+    uint32_t flags;                  /* CPT_SCENE_*                                        */
     const cpt_node* nodes;           /* host arrays, caller-owned, copied by the call      */
     const cpt_tri* tris;
     const cpt_tri_normals* tri_normals; /* n_tris entries                                  */
     const cpt_material* materials;
     cpt_camera camera;
 } cpt_scene_desc;
+
+/* cpt_upload_scene keeps the test_rank of the triangle records as given instead of deriving it from `nodes`: for a tree
+ * other than the one whose tie-breaks are wanted (the host library's fast tree carries the reference tree's ranks). */
+#define CPT_SCENE_KEEP_RANKS 1u
 
 /* ---- render parameters ---------------------------------------------------------------- */
 
@@ -172,8 +176,8 @@ int cpt_set_stream(cpt_ctx* ctx, void* hip_stream);
  * "pw_blocks" / "pw_chunk" (workgroups of the persistent extend kernel / rays a wave claims per
  * atomic, 0 = chosen from the scene size),
  * "pw_refill" / "pw_leaf_go" / "pw_full_go" (a wave of that kernel refills when this many lanes are
- * idle / runs its triangle pass when this many lanes have a parked leaf / or when this many lanes
- * cannot go on because their parked-leaf list is full). */
+ * idle / runs its triangle pass when this many lanes have a parked leaf, 0 = 32 for the reference walk and 16 for the
+ * culling walks / or when this many lanes cannot go on because their parked-leaf list is full). */
 int cpt_set_option(cpt_ctx* ctx, const char* key, long long value);
 /* Turn per-launch HIP-event timing and device-side work counters on or off (both default off). */
 int cpt_set_instrumentation(cpt_ctx* ctx, int time_kernels, int count_work);

@@ -27,6 +27,15 @@ void cpth_free(cpth_scene* s);
 
 /* Fill *out with pointers into the scene's own arrays (valid until cpth_free). */
 int cpth_describe(const cpth_scene* s, cpt_scene_desc* out);
+/* The same scene with the fast mode's tree instead of the reference's: a full-sweep surface-area build over the same
+ * triangles (about a third fewer box tests per ray on the bundled scenes, because the reference's walk tests every box a
+ * ray pierces and that is what the surface-area cost counts), the triangle records carrying the reference tree's
+ * tie-break ranks (out->flags has CPT_SCENE_KEEP_RANKS), so that every ray's closest hit -- triangle and distance -- is the
+ * one the reference's tree gives.  Visit sets and step counts are this tree's own.  Built on the first call.  No
+ * counterpart in the reference (BVHTree::build, src/scene/bvh.cpp:101-220, is its only build). */
+int cpth_describe_fast(cpth_scene* s, cpt_scene_desc* out);
+/* cpth_tree_nodes for that tree (n_tree_nodes rows as well). */
+int cpth_fast_tree_nodes(cpth_scene* s, double* boxes, int32_t* topo);
 /* width / height of the camera (reference: RayTracer::aspectRatio, src/RayTracer.cpp:549-552). */
 double cpth_aspect(const cpth_scene* s);
 /* Number of warnings collected while reading, and the k-th one. */

@@ -130,3 +130,58 @@ def test_build_is_fast_and_deterministic(host_scenes):
     assert time.time() - t0 < 5.0
     b = host_scenes("dragon-trans")
     assert a.tree()[1].tobytes() == b.tree()[1].tobytes()
+
+
+def test_fast_tree_is_a_tree_over_the_same_leaves(oracle):
+    """The fast mode's host-built tree (surface-area build): every triangle in exactly one leaf with the exact bounds of
+    its vertices, every inner box the exact union of its children's, preorder numbering, bounded height; the triangle
+    records carry the REFERENCE tree's tie-break ranks; and the oracle walking that tree finds the same hit distances
+    as on the reference tree from fewer box tests."""
+    import numpy as np
+    from conftest import scene_path
+    from cuda_path_tracer_amd import HostScene
+    for name in ["cornell-box2", "teapot-trans", "dragon-spec"]:
+        hs = HostScene(scene_path(name))
+        f = hs.fast()
+        assert f.desc.flags == 1 and f.n_tris == hs.n_tris and f.n_nodes == hs.n_tris - 1
+        boxes, topo = hs.fast_tree()
+        n = len(boxes)
+        assert n == 2 * hs.n_tris - 1 and f.tree_height <= 32
+        tris = hs.tris()
+        pts = np.stack([tris["a"], tris["b"], tris["c"]], 1)
+        seen = np.zeros(hs.n_tris, int)
+        for k in range(n - 1, -1, -1):  # children come after their parents in preorder
+            l, r, prim = topo[k]
+            if prim >= 0:
+                assert l < 0 and r < 0
+                seen[prim] += 1
+                assert np.array_equal(boxes[k, :3], pts[prim].min(0)) and np.array_equal(boxes[k, 3:], pts[prim].max(0))
+            else:
+                assert l == k + 1 and r > l
+                assert np.array_equal(boxes[k, :3], np.minimum(boxes[l, :3], boxes[r, :3]))
+                assert np.array_equal(boxes[k, 3:], np.maximum(boxes[l, 3:], boxes[r, 3:]))
+        assert (seen == 1).all()
+        # ranks: those cpt_upload_scene would derive from the reference tree
+        ref_boxes, ref_topo = hs.tree()
+        rank = np.zeros(hs.n_tris, np.uint32)
+        todo, order = [0], 0
+        while todo:
+            k = todo.pop()
+            l, r, _ = ref_topo[k]
+            if ref_topo[l, 2] >= 0:
+                rank[ref_topo[l, 2]] = 2 * order
+            if ref_topo[r, 2] >= 0:
+                rank[ref_topo[r, 2]] = 2 * order + 1
+            if ref_topo[r, 2] < 0:
+                todo.append(r)
+            if ref_topo[l, 2] < 0:
+                todo.append(l)
+            order += 1
+        assert np.array_equal(tris["test_rank"], rank)
+        orc = oracle.OracleScene(scene_path(name))
+        o, d = orc.camera_rays(40, 40)
+        a = orc.trace(o, d)
+        orc.set_tree(boxes, topo)
+        b = orc.trace(o, d)
+        assert np.array_equal(a["t"].view(np.uint64), b["t"].view(np.uint64))
+        assert b["node_steps"].sum() < a["node_steps"].sum()
