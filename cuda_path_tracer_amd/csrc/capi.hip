@@ -56,6 +56,7 @@ struct cpt_ctx {
     std::string err;
 
     void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_nodes32 = nullptr;
+    void* d_nodes_pw = nullptr;  // node records with children in stack-minimal order (or d_nodes itself)
     // Whether the tree on the device has the properties the binary32 extend variants rely on: every child box lies inside
     // its parent's box and every leaf box is exactly the bounds of its triangle's vertices (then a leaf's box passing the
     // exact test implies every box above it passes, and the root's two child boxes bound every plane of the tree).  The
@@ -68,6 +69,7 @@ struct cpt_ctx {
     DScene sc{};
     bool has_scene = false;
     int n_tree_nodes = 0, tree_height = 0, measured_height = 0;
+    int stack_need = 0;  // most node-stack entries the reference walk can hold at once on the tree in place (see minimise_stack)
 
     // A lane is everything one batch of paths needs while it is in flight.  Consecutive batches of a
     // render go to alternating lanes, each on its own HIP stream, so that the arithmetic-bound extend
@@ -135,11 +137,12 @@ static int mark_tail(cpt_ctx* c) {
 }
 
 static void free_scene(cpt_ctx* c) {
+    if (c->d_nodes_pw && c->d_nodes_pw != c->d_nodes) (void)hipFree(c->d_nodes_pw);
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_tris) (void)hipFree(c->d_tris);
     if (c->d_shade) (void)hipFree(c->d_shade);
     if (c->d_nodes32) (void)hipFree(c->d_nodes32);
-    c->d_nodes = c->d_tris = c->d_shade = c->d_nodes32 = nullptr;
+    c->d_nodes = c->d_tris = c->d_shade = c->d_nodes32 = c->d_nodes_pw = nullptr;
     c->has_scene = false;
     c->tri_ext.clear();  // the index translation belongs to the scene that is gone
     c->tri_int.clear();
@@ -270,17 +273,21 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
     return CPT_OK;
 }
 
-// Whether the persistent extend kernel can run without any global-memory record or stack traffic.
+// Which instance of the persistent extend kernel the scene in place takes: 2 when it runs without any global-memory
+// record or stack traffic, 1 when at least the node stack stays in LDS, 0 otherwise.  The reference walk postpones at
+// most stack_need nodes; the nearest-first walks choose their own order, for which only the height bounds the stack.
 // The binary32 test (3, 4) and the culling (2, 4) need a nested tree whose leaf boxes are their triangles' exact bounds: the first
 // so that a leaf's own box decides, the second so that no hit lies before the point where the ray enters a box above it or
 // the leaf's own.  On any other tree those variants run as variant 1, whose hits they would have returned.
 static bool variant_f32(const cpt_ctx* c) { return c->extend_variant >= 3 && c->tree_nested; }
 static bool variant_cull(const cpt_ctx* c) { return (c->extend_variant == 2 || c->extend_variant == 4) && c->tree_nested; }
-static int scene_resident(const cpt_ctx* c) {
-    if (!c->has_scene || c->measured_height - 2 > CPT_PW_STACK_LDS_HOST) return 0;
+static int scene_mode(const cpt_ctx* c) {
+    if (!c->has_scene) return 0;
+    const int stack = variant_cull(c) ? c->measured_height - 2 : std::min(c->stack_need, c->measured_height - 2);
+    if (stack > CPT_PW_STACK_LDS_HOST) return 0;
     // 128-byte slots the scene takes in the record cache (binary32 node records are half a slot each)
     const long long slots = variant_f32(c) ? (c->sc.n_nodes + 1) / 2 + (long long)c->sc.n_tris : (long long)c->sc.n_nodes + c->sc.n_tris;
-    return slots <= (variant_f32(c) ? CPT_PW_CACHE_RECORDS_HOST : CPT_PW_PLANAR_SLOTS_HOST);
+    return slots <= (variant_f32(c) ? CPT_PW_CACHE_RECORDS_HOST : CPT_PW_PLANAR_SLOTS_HOST) ? 2 : 1;
 }
 
 // Rays a wave claims at a time.  A claim stalls the wave for an atomic's round trip; a chunk is also what a wave may be
@@ -326,7 +333,7 @@ static const cpt_scene_desc* order_scene(cpt_ctx* c, const cpt_scene_desc* s, bo
     const int n = s->n_tris;
     if (new_order) {  // into `os`: the context keeps the old scene's tables until the old scene is gone (commit_order)
         const long long n_nodes = with_nodes ? s->n_nodes : (long long)n - 1;
-        if (n_nodes + n > CPT_PW_CACHE_RECORDS_HOST) {
+        if (n_nodes + n > CPT_PW_PLANAR_SLOTS_HOST) {
             std::vector<double> area((size_t)n);
             for (int i = 0; i < n; ++i) area[(size_t)i] = box_area_of(s->tris[i]);
             os.tri_ext.resize((size_t)n);
@@ -365,6 +372,35 @@ static const cpt_scene_desc* order_scene(cpt_ctx* c, const cpt_scene_desc* s, bo
 static void commit_order(cpt_ctx* c, OrderedScene& os) {
     c->tri_ext = std::move(os.tri_ext);
     c->tri_int = std::move(os.tri_int);
+}
+
+// The reference's walk tests both children of a node, goes on with the first that is an inner node whose box was hit and
+// postpones the other on its stack (src/gpu/GPUBVH.cu:80-97); which of the two it takes first has no influence on what
+// is tested.  While the walk is below the first child the second one occupies a stack entry, below the second nothing
+// of this node does: need(node) = max(need(first) + 1, need(second)) when both children are inner nodes, smallest when
+// the child whose subtree can itself postpone less goes first (the register-numbering argument of Sethi and Ullman,
+// mirrored).  The records are rewritten with that child in the left slot -- boxes, references and canonical ids swapped
+// together; tie-break ranks were taken from the caller's order beforehand -- and the root's need is returned: the most
+// entries the walk's stack can ever hold.  On the bundled scenes: 4 instead of 9 (teapot), 9 instead of 14 (dragon),
+// 10 instead of 15 (three dragons), against tree heights of 19 to 25.  Records come after their parents.
+static int minimise_stack(std::vector<cpt_node>& nodes) {
+    std::vector<int> need(nodes.size(), 0);
+    for (size_t k = nodes.size(); k-- > 0;) {
+        cpt_node& nd = nodes[k];
+        const bool li = nd.lref >= 0, ri = nd.rref >= 0;
+        const int nl = li ? need[(size_t)nd.lref] : 0, nr = ri ? need[(size_t)nd.rref] : 0;
+        if (li && ri) {
+            if (nl > nr) {
+                for (int q = 0; q < 6; ++q) std::swap(nd.lbox[q], nd.rbox[q]);
+                std::swap(nd.lref, nd.rref);
+                std::swap(nd.lid, nd.rid);
+            }
+            need[k] = std::max(std::max(nl, nr), std::min(nl, nr) + 1);
+        } else {
+            need[k] = std::max(nl, nr);
+        }
+    }
+    return nodes.empty() ? 0 : need[0];
 }
 
 // Whether every child box of the tree lies inside its parent's box and every leaf box equals the bounds of its
@@ -477,7 +513,7 @@ static int upload_shading(cpt_ctx* c, const cpt_scene_desc* s) {
 static int make_nodes32(cpt_ctx* c, int n_nodes) {
     if (c->d_nodes32) { (void)hipFree(c->d_nodes32); c->d_nodes32 = nullptr; }
     HIP_TRY(c, hipMalloc(&c->d_nodes32, 64 * (size_t)std::max(n_nodes, 1)));
-    launch_nodes32(c->stream, (const cpt_node*)c->d_nodes, n_nodes, c->d_nodes32);
+    launch_nodes32(c->stream, (const cpt_node*)c->d_nodes_pw, n_nodes, c->d_nodes32);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->sc.nodes32 = c->d_nodes32;
@@ -499,7 +535,14 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     HIP_TRY(c, hipMalloc(&c->d_nodes, nb));
     HIP_TRY(c, hipMalloc(&c->d_tris, sizeof(cpt_tri) * (size_t)s->n_tris));
     HIP_TRY(c, hipMalloc(&c->d_shade, sizeof(ShadeRec) * (size_t)s->n_tris));
-    if (s->n_nodes > 0) HIP_TRY(c, hipMemcpy(c->d_nodes, s->nodes, sizeof(cpt_node) * (size_t)s->n_nodes, hipMemcpyHostToDevice));
+    int stack_need = 0;
+    HIP_TRY(c, hipMalloc(&c->d_nodes_pw, nb));
+    if (s->n_nodes > 0) {
+        HIP_TRY(c, hipMemcpy(c->d_nodes, s->nodes, sizeof(cpt_node) * (size_t)s->n_nodes, hipMemcpyHostToDevice));
+        std::vector<cpt_node> nodes(s->nodes, s->nodes + s->n_nodes);
+        stack_need = minimise_stack(nodes);
+        HIP_TRY(c, hipMemcpy(c->d_nodes_pw, nodes.data(), sizeof(cpt_node) * (size_t)s->n_nodes, hipMemcpyHostToDevice));
+    }
     {   // The tie-break rank of a triangle is the position of its leaf's box test in the reference's
         // traversal order: 2 * (expansion order of the parent) + side, where nodes are expanded in
         // depth-first, left-first order.  Derived here from the node table, whatever order the records
@@ -525,6 +568,7 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     rc = upload_shading(c, s);
     if (rc != CPT_OK) return rc;
     c->sc.nodes = (const cpt_node*)c->d_nodes;
+    c->sc.nodes_pw = (const cpt_node*)c->d_nodes_pw;
     c->sc.tris = (const cpt_tri*)c->d_tris;
     c->sc.shade = (const ShadeRec*)c->d_shade;
     c->sc.cam = s->camera;
@@ -533,6 +577,7 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     c->n_tree_nodes = s->n_tree_nodes;
     c->tree_height = s->tree_height;
     c->measured_height = measured;
+    c->stack_need = stack_need;
     rc = make_nodes32(c, s->n_nodes);
     if (rc != CPT_OK) return rc;
     commit_order(c, ordered);
@@ -583,7 +628,9 @@ int cpt_build_scene(cpt_ctx* c, const cpt_scene_desc* s) {
         if (height > CPT_MAX_TREE_HEIGHT)
             return fail(c, CPT_ELIMIT, "tree height %d needs a %d-entry stack; limit is %d", height, height - 2, CPT_STACK_ENTRIES_HOST);
     }
+    c->d_nodes_pw = c->d_nodes;  // a tree built on the device is walked in the order it was built in
     c->sc.nodes = (const cpt_node*)c->d_nodes;
+    c->sc.nodes_pw = (const cpt_node*)c->d_nodes_pw;
     c->sc.tris = (const cpt_tri*)c->d_tris;
     c->sc.shade = (const ShadeRec*)c->d_shade;
     c->sc.cam = s->camera;
@@ -592,6 +639,7 @@ int cpt_build_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     c->n_tree_nodes = 2 * n - 1;
     c->tree_height = height;
     c->measured_height = height;
+    c->stack_need = height;  // not worked out for a tree built on the device: the height bounds it
     rc = make_nodes32(c, n - 1);
     if (rc != CPT_OK) return rc;
     commit_order(c, ordered);
@@ -650,6 +698,12 @@ int cpt_refit_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     if (e != hipSuccess) return fail(c, CPT_EHIP, "refit: %s", hipGetErrorString(e));
     rc = upload_shading(c, s);
     if (rc != CPT_OK) return rc;
+    if (m > 0 && c->d_nodes_pw != c->d_nodes) {  // the walk's copy of the records: same child order as before, new boxes
+        std::vector<cpt_node> fresh((size_t)m);
+        HIP_TRY(c, hipMemcpy(fresh.data(), c->d_nodes, sizeof(cpt_node) * (size_t)m, hipMemcpyDeviceToHost));
+        c->stack_need = minimise_stack(fresh);  // the need depends on the topology alone, so the order comes out the same
+        HIP_TRY(c, hipMemcpy(c->d_nodes_pw, fresh.data(), sizeof(cpt_node) * (size_t)m, hipMemcpyHostToDevice));
+    }
     rc = make_nodes32(c, m);  // the boxes changed
     if (rc != CPT_OK) return rc;
     c->sc.cam = s->camera;
@@ -863,7 +917,7 @@ static int run_wavefront(cpt_ctx* c, const DParams& P, LaunchCfg L, cpt_ctx::Lan
 static int leaf_go_for(const cpt_ctx* c) { return c->pw_leaf_go > 0 ? c->pw_leaf_go : (variant_cull(c) ? 16 : 32); }
 
 static LaunchCfg launch_cfg(const cpt_ctx* c) {
-    return LaunchCfg{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_resident(c), variant_cull(c), variant_f32(c), c->pw_full_go, leaf_go_for(c)};
+    return LaunchCfg{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_mode(c), variant_cull(c), variant_f32(c), c->pw_full_go, leaf_go_for(c)};
 }
 
 int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {

@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
 // go to a per-lane column of `spill` in global memory.
 #define CPT_PW_THREADS CPT_PW_THREADS_HOST
 #define CPT_PW_WAVES (CPT_PW_THREADS / CPT_WAVE)
-#define CPT_PW_CACHE_RECORDS CPT_PW_CACHE_RECORDS_HOST  // 64 KB of 128-byte records
+#define CPT_PW_CACHE_RECORDS CPT_PW_CACHE_RECORDS_HOST  // 66 KB of 128-byte records
 #ifndef CPT_PW_BOX_REPEAT
 #define CPT_PW_BOX_REPEAT 3   // node expansions per lane and loop turn
 #endif
@@ -227,11 +227,11 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
 #ifndef CPT_PW_HOT_TRIS
 #define CPT_PW_HOT_TRIS 32    // record-cache slots kept for triangles when the node records alone would fill it
 #endif
-// How an instance of the persistent kernel divides the CU's 160 KB of LDS: 64 KB of scene records, 12 node-stack entries
-// and 10 parked leaves per lane (88 KB).  The exact variants keep the records as seven planes (planar_record), which
+// How an instance of the persistent kernel divides the CU's 160 KB of LDS: 66 KB of scene records, 12 node-stack entries
+// and 10 parked leaves per lane (88 KB); the 6 KB left over are what the shade workgroups running beside it need.  The exact variants keep the records as seven planes (planar_record), which
 // holds CPT_PW_PLANAR_SLOTS_HOST of them because the never-read eighth piece is not stored; the binary32 variants keep
 // CPT_PW_CACHE_RECORDS whole 128-byte slots (two 64-byte node records per slot).
-template <bool RESIDENT, bool F32>
+template <bool F32>
 struct PwPlan {
     static constexpr int STACK_LDS = CPT_PW_STACK_LDS_HOST;  // node-stack entries per lane in LDS
     static constexpr int LEAF_CAP = CPT_PW_LEAF_CAP;         // parked leaves per lane (a node expansion adds at most two)
@@ -425,16 +425,20 @@ __device__ __forceinline__ void slab32_pair(v2f lox, v2f loy, v2f loz, v2f hix, 
 // a box the ray enters beyond the closest hit found so far (with a relative margin of 1e-6) is not
 // walked at all.  The closest hit is the same one; the set of visited nodes, which the reference
 // mode reproduces exactly, is not.
+// MODE (checked by the host, see scene_mode): 2 = RESIDENT, the whole scene is in the record cache and the walk's node
+// stack never needs more than its LDS entries; 1 = the stack fits its LDS entries but records may have to come from
+// global memory; 0 = neither.  Instances with an LDS-only stack address it by pointer and have no spill path.
 // RESIDENT: the whole scene is in the record cache and its tree is low enough for the LDS part of the node
 // stack, so the loop has no vector-memory record or spill path and none of the waits that come with
 // them; the only loads left are the rays.
 // F32: inner nodes through the conservative binary32 test, leaves through the exact test of their own box (see above).
-template <bool COUNT, bool CULL, bool RESIDENT, bool F32>
+template <bool COUNT, bool CULL, int MODE, bool F32>
 __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStream in, HitBuf hit,
                                                               const uint32_t* __restrict__ counter, uint32_t* cursor, uint32_t cap,
                                                               uint32_t chunk, uint32_t refill_at, uint32_t leaf_go, uint32_t full_go, uint32_t* spill, unsigned long long* work,
                                                               ExtendObserve obs) {
-    typedef PwPlan<RESIDENT, F32> Plan;
+    constexpr bool RESIDENT = MODE == 2, LDS_STACK = MODE >= 1;
+    typedef PwPlan<F32> Plan;
     constexpr int kStackLds = Plan::STACK_LDS, kLeafCap = Plan::LEAF_CAP;
     constexpr int kPlaneBytes = F32 ? 0 : Plan::PLANE_BYTES;  // 0: whole records with rotated pieces (fetch_record)
     __shared__ __attribute__((aligned(128))) unsigned char s_cache[Plan::CACHE_BYTES];
@@ -479,7 +483,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     } else {
         for (int i = (int)threadIdx.x; i < (cached_nodes + cached_tris) * 8; i += CPT_PW_THREADS) {
             int r = i >> 3, c = i & 7;
-            const unsigned char* src = r < cached_nodes ? (const unsigned char*)sc.nodes + (size_t)r * 128
+            const unsigned char* src = r < cached_nodes ? (const unsigned char*)sc.nodes_pw + (size_t)r * 128
                                                         : (const unsigned char*)sc.tris + (size_t)(r - cached_nodes) * 128;
             if (c < 7) *(double2*)(s_cache + (size_t)c * Plan::PLANE_BYTES + (size_t)r * 16) = *(const double2*)(src + c * 16);  // planar, see planar_record
         }
@@ -488,7 +492,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     // binary32 test's error margins
     float scene_extent = 0.0f;
     if (F32 && sc.n_nodes > 0) {
-        const double* b = (const double*)sc.nodes;
+        const double* b = (const double*)sc.nodes_pw;
         double m = 0.0;
         for (int k = 0; k < 12; ++k) m = fmax(m, fabs(b[k]));
         scene_extent = f32_up(m);
@@ -503,7 +507,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     lds_u32* leaf_top = leaf_base;
 #define CPT_LEAVES_AT_MOST(N) (leaf_top <= leaf_base + (N) * CPT_WAVE)
 
-    // likewise the node stack of the RESIDENT instances (the others count entries: theirs continues in global memory)
+    // likewise the node stack of the instances whose stack never outgrows LDS (the others count entries: theirs continues in global memory)
     lds_u32* const node_base = (lds_u32*)&s_nodes[wave][0][lane];
     lds_u32* node_top = node_base;
     uint32_t* my_spill = spill + (size_t)blockIdx.x * CPT_PW_THREADS + threadIdx.x;  // entry e at my_spill[e * spill_stride]
@@ -601,7 +605,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                     enter_l = (double)el;
                     enter_r = (double)er;
                 } else {
-                    const Rec7 r = fetch_record<RESIDENT, kPlaneBytes>(sc.nodes, cache, 0, cached_nodes, node);
+                    const Rec7 r = fetch_record<RESIDENT, kPlaneBytes>(sc.nodes_pw, cache, 0, cached_nodes, node);
                     refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));
                     ids = make_int2(__double2loint(r.p6.y), __double2hiint(r.p6.y));
                     bool sure_l, sure_r;
@@ -639,7 +643,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 *leaf_top = (uint32_t)refs.y;
                 leaf_top += (hr && refs.y < 0) ? CPT_WAVE : 0;
                 bool tl = hl && refs.x >= 0, tr = hr && refs.y >= 0;
-                if (RESIDENT) {
+                if (LDS_STACK) {
                     if (tl) {
                         node = refs.x;
                         if (tr) { *node_top = (uint32_t)refs.y; node_top += CPT_WAVE; }
@@ -983,26 +987,24 @@ void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in,
     hipLaunchKernelGGL((k_extend_pw<COUNT, CULL, RES, F32>), dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, \
                        cursor, cap, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go,                       \
                        (uint32_t)L.pw_full_go, spill, work, obs)
-    const bool resident = L.pw_resident != 0;
-    const int which = (L.pw_f32 ? 8 : 0) | (work ? 4 : 0) | (L.pw_cull ? 2 : 0) | (resident ? 1 : 0);
-    switch (which) {
-        case 0: CPT_PW_LAUNCH(false, false, false, false); break;
-        case 1: CPT_PW_LAUNCH(false, false, true, false); break;
-        case 2: CPT_PW_LAUNCH(false, true, false, false); break;
-        case 3: CPT_PW_LAUNCH(false, true, true, false); break;
-        case 4: CPT_PW_LAUNCH(true, false, false, false); break;
-        case 5: CPT_PW_LAUNCH(true, false, true, false); break;
-        case 6: CPT_PW_LAUNCH(true, true, false, false); break;
-        case 7: CPT_PW_LAUNCH(true, true, true, false); break;
-        case 8: CPT_PW_LAUNCH(false, false, false, true); break;
-        case 9: CPT_PW_LAUNCH(false, false, true, true); break;
-        case 10: CPT_PW_LAUNCH(false, true, false, true); break;
-        case 11: CPT_PW_LAUNCH(false, true, true, true); break;
-        case 12: CPT_PW_LAUNCH(true, false, false, true); break;
-        case 13: CPT_PW_LAUNCH(true, false, true, true); break;
-        case 14: CPT_PW_LAUNCH(true, true, false, true); break;
-        default: CPT_PW_LAUNCH(true, true, true, true); break;
+#define CPT_PW_LAUNCH_MODE(COUNT, CULL, F32)                         \
+    switch (L.pw_mode) {                                             \
+        case 2: CPT_PW_LAUNCH(COUNT, CULL, 2, F32); break;           \
+        case 1: CPT_PW_LAUNCH(COUNT, CULL, 1, F32); break;           \
+        default: CPT_PW_LAUNCH(COUNT, CULL, 0, F32); break;          \
     }
+    const int which = (L.pw_f32 ? 4 : 0) | (work ? 2 : 0) | (L.pw_cull ? 1 : 0);
+    switch (which) {
+        case 0: CPT_PW_LAUNCH_MODE(false, false, false); break;
+        case 1: CPT_PW_LAUNCH_MODE(false, true, false); break;
+        case 2: CPT_PW_LAUNCH_MODE(true, false, false); break;
+        case 3: CPT_PW_LAUNCH_MODE(true, true, false); break;
+        case 4: CPT_PW_LAUNCH_MODE(false, false, true); break;
+        case 5: CPT_PW_LAUNCH_MODE(false, true, true); break;
+        case 6: CPT_PW_LAUNCH_MODE(true, false, true); break;
+        default: CPT_PW_LAUNCH_MODE(true, true, true); break;
+    }
+#undef CPT_PW_LAUNCH_MODE
 #undef CPT_PW_LAUNCH
 }
 void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& in, const HitBuf& hit,

@@ -54,7 +54,9 @@ CPT_HD LobeProb lobe_probabilities(const double* kd3, const double* ks3, const d
 }
 
 struct DScene {
-    const cpt_node* __restrict__ nodes;
+    const cpt_node* __restrict__ nodes;      // the tree as the caller (or the device build) gave it: hooks, one-ray-per-thread kernels
+    const cpt_node* __restrict__ nodes_pw;   // the same records with each node's children in stack-minimal order (persistent extend kernel);
+                                             // the same array when no such copy was made
     const cpt_tri* __restrict__ tris;       // intersection records (extend)
     const ShadeRec* __restrict__ shade;     // shading records (shade), one per triangle
     const void* __restrict__ nodes32;       // 64-byte binary32 copies of the node records, boxes rounded outwards (extend variants 3 and 4)
@@ -135,10 +137,10 @@ struct Radiance {           // radiance gathered per path, indexed by slot; touc
 inline uint32_t cpt_segment_cap(size_t n) { return (uint32_t)(((n + CPT_PW_SEGMENTS - 1) / CPT_PW_SEGMENTS + 63) / 64 * 64); }
 inline size_t cpt_stream_positions(size_t n) { return (size_t)cpt_segment_cap(n) * CPT_PW_SEGMENTS; }
 #ifndef CPT_PW_CACHE_RECORDS_HOST
-#define CPT_PW_CACHE_RECORDS_HOST 512  // 128-byte records of the scene the persistent extend kernel keeps in LDS (its 64 KB record cache) ...
+#define CPT_PW_CACHE_RECORDS_HOST 528  // 128-byte records of the scene the persistent extend kernel keeps in LDS (its 66 KB record cache) ...
 #endif
 // ... and how many the exact variants keep, which store only the seven 16-byte pieces of a record that are ever read
-// (585 for 64 KB; kept odd, see planar_record)
+// (603 for 66 KB; kept odd, see planar_record)
 #define CPT_PW_PLANAR_SLOTS_HOST (((CPT_PW_CACHE_RECORDS_HOST * 128 / 112) & 1) ? (CPT_PW_CACHE_RECORDS_HOST * 128 / 112) : (CPT_PW_CACHE_RECORDS_HOST * 128 / 112) - 1)
 #ifndef CPT_PW_THREADS_HOST
 #define CPT_PW_THREADS_HOST 1024
@@ -159,7 +161,7 @@ struct LaunchCfg {
     int pw_blocks;   // number of persistent 1024-thread workgroups of k_extend_pw (one per CU)
     int pw_chunk;    // queue entries a wave takes per atomic
     int pw_refill;   // a wave refills when at least this many of its lanes are idle
-    int pw_resident; // 1: scene fits the LDS record cache and its node stack fits the LDS entries (checked by the host)
+    int pw_mode;     // 2: the scene fits the LDS record cache and the walk's stack its LDS entries; 1: the stack only; 0: neither (checked by the host)
     int pw_cull;     // 1: nearest-first walk with closest-hit culling (fast mode), 0: the reference's visit set
     int pw_f32;      // 1: inner nodes through the conservative binary32 test, leaves through the exact test of their own box
     int pw_full_go;  // ... or when at least this many lanes cannot expand a node because their parked-leaf list is full

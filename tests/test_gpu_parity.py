@@ -902,6 +902,54 @@ def test_deep_stacks_spill_past_the_lds_entries(tmp_path, gpu, oracle):
         gpu.set_option("extend_variant", 1)
 
 
+def test_balanced_row_of_cards_needs_the_spill_columns_under_any_child_order(tmp_path, gpu, oracle):
+    """The persistent extend kernel takes each node's children in the order that keeps its stack shortest, which brings
+    the bundled scenes' needs (4 to 10 entries) under the 12 entries it holds in LDS.  The reference's nearly balanced tree
+    over 2^15 cards in an evenly spaced row needs 13 whichever child goes first (worked out below from its topology), and
+    rays along the row do pierce every box: the instance with the global-memory stack columns is the one that runs, for
+    the reference walk too, and its hits and visit sets are the oracle's."""
+    from cuda_path_tracer_amd import HostScene
+    n_cards = 1 << 15
+    pts, faces = [], []
+    for i in range(n_cards):
+        x = 0.01 * i
+        pts += ["(%r,-1,-1)" % x, "(%r,1,-1)" % x, "(%r,0,1)" % x]
+        faces.append("(%d,%d,%d)" % (3 * i, 3 * i + 1, 3 * i + 2))
+    text = ("SBT-raytracer 1.0\ncamera { position = (-5,0,0); viewdir = (1,0,0); updir = (0,1,0); }\n"
+            "polymesh { material = { diffuse = (0.5,0.5,0.5); transmissive = (0.5,0.5,0.5); index = 1.0; };\n"
+            " points = (%s); faces = (%s); }\n" % (",".join(pts), ",".join(faces)))
+    path = tmp_path / "row.ray"
+    path.write_text(text)
+    orc = oracle.OracleScene(str(path))
+    hs = HostScene(str(path))
+    topo = hs.tree()[1]
+    need = np.zeros(len(topo), int)  # fewest stack entries a depth-first walk of the subtree can do with
+    for k in range(len(topo) - 1, -1, -1):
+        l, r, prim = topo[k]
+        if prim < 0:
+            nl = need[l] if topo[l, 2] < 0 else 0
+            nr = need[r] if topo[r, 2] < 0 else 0
+            need[k] = max(max(nl, nr), min(nl, nr) + 1) if (topo[l, 2] < 0 and topo[r, 2] < 0) else max(nl, nr)
+    assert need[0] == 13
+    gpu.upload(hs)
+    rng = np.random.default_rng(4)
+    n = 300
+    o = np.column_stack([np.full(n, -5.0), rng.uniform(-0.5, 0.5, n), rng.uniform(-0.5, 0.5, n)])
+    d = np.column_stack([np.ones(n), rng.normal(0, 0.001, n), rng.normal(0, 0.001, n)])
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    want = orc.trace(o, d)
+    assert int(want["max_stack"].max()) >= 13
+    try:
+        for variant in (1, 0, 2):
+            gpu.set_option("extend_variant", variant)
+            got = gpu.extend_rays_observed(o, d)
+            assert np.array_equal(got["prim"], want["prim"]) and np.array_equal(bits(got["t"]), bits(want["t"])), variant
+            if variant != 2:
+                assert np.array_equal(got["vhash"], want["vhash"]), variant
+    finally:
+        gpu.set_option("extend_variant", 1)
+
+
 def test_stream_handover_does_not_touch_the_previous_stream(gpu_scene):
     """cpt_set_stream orders the new stream behind the context's earlier work through an event of the context's own,
     not through the previous stream's handle: the previous stream may be gone by then (a torch stream that went out
