@@ -108,6 +108,8 @@ struct cpt_ctx {
     int pw_blocks = 0;             // persistent workgroups of the extend kernel (one per CU)
     int pw_chunk = 0;              // rays a persistent wave claims per atomic; 0: chosen from the scene, see chunk_for
     int pw_refill = 12, pw_leaf_go = 0, pw_full_go = 1;  // pw_leaf_go 0: chosen from the walk, see leaf_go_for
+    int pw_box_repeat = 0;  // 0: chosen from the tree, see box_repeat_for
+    bool caller_ranks = false;  // the scene in place was uploaded with CPT_SCENE_KEEP_RANKS (a tree other than the reference's)
     int extend_variant = 1;        // 0: one ray per thread; 1: persistent waves with refill; 2: as 1, nearest-first with culling
 };
 
@@ -261,6 +263,9 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
     } else if (!strcmp(key, "pw_full_go")) {
         if (value < 1 || value > 64) return fail(c, CPT_EINVAL, "pw_full_go must be in [1, 64]");
         c->pw_full_go = (int)value;
+    } else if (!strcmp(key, "pw_box_repeat")) {
+        if (value != 0 && value != 2 && value != 3) return fail(c, CPT_EINVAL, "pw_box_repeat must be 0 (automatic), 2 or 3");
+        c->pw_box_repeat = (int)value;
     } else if (!strcmp(key, "pw_leaf_go")) {
         if (value < 0 || value > 64) return fail(c, CPT_EINVAL, "pw_leaf_go must be in [0, 64]");
         c->pw_leaf_go = (int)value;
@@ -582,6 +587,7 @@ int cpt_upload_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     if (rc != CPT_OK) return rc;
     commit_order(c, ordered);
     c->tree_nested = nested;
+    c->caller_ranks = (s->flags & CPT_SCENE_KEEP_RANKS) != 0;
     c->has_scene = true;
     return CPT_OK;
 }
@@ -644,6 +650,7 @@ int cpt_build_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     if (rc != CPT_OK) return rc;
     commit_order(c, ordered);
     c->tree_nested = true;  // the build's boxes are exact unions, leaf boxes exact bounds
+    c->caller_ranks = false;
     c->has_scene = true;
     return CPT_OK;
 }
@@ -916,8 +923,14 @@ static int run_wavefront(cpt_ctx* c, const DParams& P, LaunchCfg L, cpt_ctx::Lan
 // (measured on the 10 000-triangle scene over the surface-area tree: 16 is 3 % faster than 32, 8 the same as 16).
 static int leaf_go_for(const cpt_ctx* c) { return c->pw_leaf_go > 0 ? c->pw_leaf_go : (variant_cull(c) ? 16 : 32); }
 
+// Node expansions per lane between two looks at the triangle phase.  A turn of the kernel's loop runs at most one triangle
+// pass, so the ratio fixes how many triangle tests per node step the loop can absorb before lanes wait with parked leaves: on
+// the reference's trees (4 node steps per triangle test on the bundled scenes) three expansions per turn are best, on the
+// surface-area tree's shorter walks (3 per test) two are (cfg2 +3.5 %, teapot +2 % there; 1.5-3 % worse on the reference tree).
+static int box_repeat_for(const cpt_ctx* c) { return c->pw_box_repeat ? c->pw_box_repeat : (c->caller_ranks ? 2 : 3); }
+
 static LaunchCfg launch_cfg(const cpt_ctx* c) {
-    return LaunchCfg{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_mode(c), variant_cull(c), variant_f32(c), c->pw_full_go, leaf_go_for(c)};
+    return LaunchCfg{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_mode(c), variant_cull(c), variant_f32(c), c->pw_full_go, leaf_go_for(c), box_repeat_for(c)};
 }
 
 int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {

@@ -218,9 +218,6 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_extend(DScene sc, RayStream in, H
 #define CPT_PW_THREADS CPT_PW_THREADS_HOST
 #define CPT_PW_WAVES (CPT_PW_THREADS / CPT_WAVE)
 #define CPT_PW_CACHE_RECORDS CPT_PW_CACHE_RECORDS_HOST  // 66 KB of 128-byte records
-#ifndef CPT_PW_BOX_REPEAT
-#define CPT_PW_BOX_REPEAT 3   // node expansions per lane and loop turn
-#endif
 #ifndef CPT_PW_LEAF_CAP
 #define CPT_PW_LEAF_CAP 10
 #endif
@@ -432,7 +429,7 @@ __device__ __forceinline__ void slab32_pair(v2f lox, v2f loy, v2f loz, v2f hix, 
 // stack, so the loop has no vector-memory record or spill path and none of the waits that come with
 // them; the only loads left are the rays.
 // F32: inner nodes through the conservative binary32 test, leaves through the exact test of their own box (see above).
-template <bool COUNT, bool CULL, int MODE, bool F32>
+template <bool COUNT, bool CULL, int MODE, bool F32, int REPS>
 __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStream in, HitBuf hit,
                                                               const uint32_t* __restrict__ counter, uint32_t* cursor, uint32_t cap,
                                                               uint32_t chunk, uint32_t refill_at, uint32_t leaf_go, uint32_t full_go, uint32_t* spill, unsigned long long* work,
@@ -579,11 +576,11 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
         }
     
 
-        // ---- box phase: expand up to CPT_PW_BOX_REPEAT nodes per lane that has one (and room to park two more leaves) ----
+        // ---- box phase: expand up to REPS nodes per lane that has one (and room to park two more leaves) ----
         // (several expansions per turn of the loop spread its fixed costs -- ballots, refill and triangle-pass
         // decisions -- over more node steps)
 #pragma unroll
-        for (int rep = 0; rep < CPT_PW_BOX_REPEAT; ++rep) {
+        for (int rep = 0; rep < REPS; ++rep) {
             const bool boxing = node >= 0 && CPT_LEAVES_AT_MOST(kLeafCap - 2);
             if (COUNT) {
                 uint64_t any_boxing = __ballot(boxing);
@@ -983,15 +980,18 @@ void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, co
 void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
                       uint32_t cap, uint32_t* cursor, uint32_t* spill, unsigned long long* work, const ExtendObserve& obs) {
     int g = L.pw_blocks;
-#define CPT_PW_LAUNCH(COUNT, CULL, RES, F32)                                                                                  \
-    hipLaunchKernelGGL((k_extend_pw<COUNT, CULL, RES, F32>), dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, \
+#define CPT_PW_LAUNCH(COUNT, CULL, RES, F32, REPS)                                                                                  \
+    hipLaunchKernelGGL((k_extend_pw<COUNT, CULL, RES, F32, REPS>), dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, \
                        cursor, cap, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go,                       \
                        (uint32_t)L.pw_full_go, spill, work, obs)
-#define CPT_PW_LAUNCH_MODE(COUNT, CULL, F32)                         \
-    switch (L.pw_mode) {                                             \
-        case 2: CPT_PW_LAUNCH(COUNT, CULL, 2, F32); break;           \
-        case 1: CPT_PW_LAUNCH(COUNT, CULL, 1, F32); break;           \
-        default: CPT_PW_LAUNCH(COUNT, CULL, 0, F32); break;          \
+#define CPT_PW_LAUNCH_REPS(COUNT, CULL, MODE, F32)                                   \
+    if (L.pw_box_repeat == 2) CPT_PW_LAUNCH(COUNT, CULL, MODE, F32, 2);                 \
+    else CPT_PW_LAUNCH(COUNT, CULL, MODE, F32, 3)
+#define CPT_PW_LAUNCH_MODE(COUNT, CULL, F32)                                            \
+    switch (L.pw_mode) {                                                                \
+        case 2: CPT_PW_LAUNCH_REPS(COUNT, CULL, 2, F32); break;                         \
+        case 1: CPT_PW_LAUNCH_REPS(COUNT, CULL, 1, F32); break;                         \
+        default: CPT_PW_LAUNCH_REPS(COUNT, CULL, 0, F32); break;                        \
     }
     const int which = (L.pw_f32 ? 4 : 0) | (work ? 2 : 0) | (L.pw_cull ? 1 : 0);
     switch (which) {
@@ -1005,6 +1005,7 @@ void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in,
         default: CPT_PW_LAUNCH_MODE(true, true, true); break;
     }
 #undef CPT_PW_LAUNCH_MODE
+#undef CPT_PW_LAUNCH_REPS
 #undef CPT_PW_LAUNCH
 }
 void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& in, const HitBuf& hit,

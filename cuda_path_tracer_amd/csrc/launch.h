@@ -166,6 +166,7 @@ struct LaunchCfg {
     int pw_f32;      // 1: inner nodes through the conservative binary32 test, leaves through the exact test of their own box
     int pw_full_go;  // ... or when at least this many lanes cannot expand a node because their parked-leaf list is full
     int pw_leaf_go;  // a wave runs its triangle phase when at least this many lanes have a parked leaf
+    int pw_box_repeat; // node expansions per lane between two looks at the triangle phase: 2 or 3 (compiled instances)
 };
 
 void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& out, const Radiance& col,

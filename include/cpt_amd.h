@@ -175,6 +175,8 @@ int cpt_set_stream(cpt_ctx* ctx, void* hip_stream);
  * so variants 0 and 1, take as they come) the context runs 2, 3 and 4 as 1),
  * "pw_blocks" / "pw_chunk" (workgroups of the persistent extend kernel / rays a wave claims per
  * atomic, 0 = chosen from the scene size),
+ * "pw_box_repeat" (node expansions per lane between two looks at the triangle phase: 3 or 2; 0 = 3, or 2 for a tree
+ * uploaded with CPT_SCENE_KEEP_RANKS, whose walks are shorter),
  * "pw_refill" / "pw_leaf_go" / "pw_full_go" (a wave of that kernel refills when this many lanes are
  * idle / runs its triangle pass when this many lanes have a parked leaf, 0 = 32 for the reference walk and 16 for the
  * culling walks / or when this many lanes cannot go on because their parked-leaf list is full). */
