@@ -520,7 +520,7 @@ size_t lbvh_work_bytes(int n_tris) { return carve(nullptr, n_tris).bytes; }
 // `morton_bits` per axis in [0, 10].  *h_height receives the tree's height in levels (root = 1) after a
 // synchronisation of `st`.  n_tris >= 2.
 hipError_t launch_lbvh_build(hipStream_t st, cpt_tri* d_tris, int n_tris, cpt_node* d_nodes, void* d_work, int morton_bits,
-                             int* h_height) {
+                             int* h_height, bool keep_ranks) {
     const int n = n_tris, m = n - 1;
     Work w = carve((char*)d_work, n);
     hipError_t e;
@@ -556,7 +556,8 @@ hipError_t launch_lbvh_build(hipStream_t st, cpt_tri* d_tris, int n_tris, cpt_no
         k_fit_level<<<blocks, LB_THREADS, 0, st>>>(w.keys_c, w.level_start, level, src, d_tris, w.left, w.right, w.node_id, w.leaf_id,
                                                    w.new_index, d_nodes);
     }
-    k_ranks<<<gn, LB_THREADS, 0, st>>>(src, n, w.right, w.parent_leaf, w.node_order, d_tris);
+    // keep_ranks: the triangle records came with the tie-break ranks of another tree (the reference's) and keep them
+    if (!keep_ranks) k_ranks<<<gn, LB_THREADS, 0, st>>>(src, n, w.right, w.parent_leaf, w.node_order, d_tris);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
     *h_height = (int)leaf_depth + 1;

@@ -626,7 +626,8 @@ int cpt_build_scene(cpt_ctx* c, const cpt_scene_desc* s) {
         // at all the tree is the balanced one over the input order.
         hipError_t e = hipSuccess;
         for (int bits = 10; bits >= 0; bits -= 2) {
-            e = launch_lbvh_build(c->stream, (cpt_tri*)c->d_tris, n, (cpt_node*)c->d_nodes, work, bits, &height);
+            e = launch_lbvh_build(c->stream, (cpt_tri*)c->d_tris, n, (cpt_node*)c->d_nodes, work, bits, &height,
+                                  (s->flags & CPT_SCENE_KEEP_RANKS) != 0);
             if (e != hipSuccess || height <= CPT_MAX_TREE_HEIGHT) break;
         }
         (void)hipFree(work);
@@ -634,7 +635,19 @@ int cpt_build_scene(cpt_ctx* c, const cpt_scene_desc* s) {
         if (height > CPT_MAX_TREE_HEIGHT)
             return fail(c, CPT_ELIMIT, "tree height %d needs a %d-entry stack; limit is %d", height, height - 2, CPT_STACK_ENTRIES_HOST);
     }
-    c->d_nodes_pw = c->d_nodes;  // a tree built on the device is walked in the order it was built in
+    // The persistent kernel's copy with the children in stack-minimal order is made on the host (one pass over the
+    // records); for very large trees the round trip is not worth it and the tree is walked as built, its height bounding the stack.
+    c->d_nodes_pw = c->d_nodes;
+    int stack_need = height;
+    if (n - 1 > 0 && n - 1 <= (1 << 18)) {
+        std::vector<cpt_node> built((size_t)(n - 1));
+        HIP_TRY(c, hipMemcpy(built.data(), c->d_nodes, sizeof(cpt_node) * built.size(), hipMemcpyDeviceToHost));
+        stack_need = minimise_stack(built);
+        void* pw = nullptr;
+        HIP_TRY(c, hipMalloc(&pw, sizeof(cpt_node) * built.size()));
+        c->d_nodes_pw = pw;
+        HIP_TRY(c, hipMemcpy(c->d_nodes_pw, built.data(), sizeof(cpt_node) * built.size(), hipMemcpyHostToDevice));
+    }
     c->sc.nodes = (const cpt_node*)c->d_nodes;
     c->sc.nodes_pw = (const cpt_node*)c->d_nodes_pw;
     c->sc.tris = (const cpt_tri*)c->d_tris;
@@ -645,12 +658,12 @@ int cpt_build_scene(cpt_ctx* c, const cpt_scene_desc* s) {
     c->n_tree_nodes = 2 * n - 1;
     c->tree_height = height;
     c->measured_height = height;
-    c->stack_need = height;  // not worked out for a tree built on the device: the height bounds it
+    c->stack_need = stack_need;
     rc = make_nodes32(c, n - 1);
     if (rc != CPT_OK) return rc;
     commit_order(c, ordered);
     c->tree_nested = true;  // the build's boxes are exact unions, leaf boxes exact bounds
-    c->caller_ranks = false;
+    c->caller_ranks = (s->flags & CPT_SCENE_KEEP_RANKS) != 0;
     c->has_scene = true;
     return CPT_OK;
 }

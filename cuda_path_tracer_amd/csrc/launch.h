@@ -197,4 +197,4 @@ void launch_update_tris(hipStream_t st, const cpt_tri* d_fresh, int n_tris, cpt_
 void launch_refit(hipStream_t st, const int* d_order, const int* level_start, int n_levels, const cpt_tri* d_tris, cpt_node* d_nodes);
 size_t lbvh_work_bytes(int n_tris);
 hipError_t launch_lbvh_build(hipStream_t st, cpt_tri* d_tris, int n_tris, cpt_node* d_nodes, void* d_work, int morton_bits,
-                             int* h_height);
+                             int* h_height, bool keep_ranks);

@@ -72,9 +72,16 @@ class Renderer:
         self._check(self._L.cpt_upload_scene(self._h, C.byref(host_scene.desc)), "cpt_upload_scene")
         self._scene = host_scene  # keeps the host arrays alive, and n_tree_nodes for bitmaps
 
-    def build(self, host_scene):
-        """Upload triangles, materials and camera and build the BVH on the GPU (the host scene's own tree is not used)."""
-        self._check(self._L.cpt_build_scene(self._h, C.byref(host_scene.desc)), "cpt_build_scene")
+    def build(self, host_scene, keep_ranks=False):
+        """Upload triangles, materials and camera and build the BVH on the GPU (the host scene's own tree is not used).
+        keep_ranks: the triangle records' tie-break ranks (the reference tree's, as HostScene fills them in) are kept, so
+        that ties between equal hits fall as on the reference's tree."""
+        desc = host_scene.desc
+        if keep_ranks:
+            desc = _capi.SceneDesc()
+            C.memmove(C.byref(desc), C.byref(host_scene.desc), C.sizeof(desc))
+            desc.flags |= 1  # CPT_SCENE_KEEP_RANKS
+        self._check(self._L.cpt_build_scene(self._h, C.byref(desc)), "cpt_build_scene")
         self._scene = host_scene
 
     def refit(self, host_scene):

@@ -100,8 +100,9 @@ typedef struct cpt_scene_desc {
     cpt_camera camera;
 } cpt_scene_desc;
 
-/* cpt_upload_scene keeps the test_rank of the triangle records as given instead of deriving it from `nodes`: for a tree
- * other than the one whose tie-breaks are wanted (the host library's fast tree carries the reference tree's ranks). */
+/* cpt_upload_scene and cpt_build_scene keep the test_rank of the triangle records as given instead of deriving it from
+ * the tree: for a tree other than the one whose tie-breaks are wanted (the host library's fast tree, or a tree built on
+ * the device, carrying the reference tree's ranks). */
 #define CPT_SCENE_KEEP_RANKS 1u
 
 /* ---- render parameters ---------------------------------------------------------------- */
@@ -193,8 +194,10 @@ int cpt_upload_scene(cpt_ctx* ctx, const cpt_scene_desc* scene);
  * `BVHTree::build` (reference: src/scene/bvh.cpp:101-220) together with the upload above, for callers
  * that do not need the reference's tree: the result is a Morton-order tree with exact boxes, so renders
  * are statistically the same image but visit sets, step counts and the winner among equal-t hits are
- * this tree's own.  A tree too tall for the traversal stacks is rebuilt with coarser Morton codes;
- * CPT_ELIMIT if even that fails.  Synchronous. */
+ * this tree's own -- unless scene->flags has CPT_SCENE_KEEP_RANKS and the triangle records carry the tie-break ranks of
+ * the reference's tree (the host library fills them in): then every ray's closest hit, ties included, is the one the
+ * reference's tree gives, and the image is the same bit for bit.  A tree too tall for the traversal stacks is rebuilt
+ * with coarser Morton codes; CPT_ELIMIT if even that fails.  Synchronous. */
 int cpt_build_scene(cpt_ctx* ctx, const cpt_scene_desc* scene);
 
 /* New vertices (and normals, materials, camera) for the scene on the GPU, same triangles in the same order, same

@@ -269,6 +269,41 @@ def test_tall_morton_chain_is_rebuilt_with_coarser_codes(gpu, oracle, tmp_path):
     compare_with_oracle_on_same_tree(gpu, orc, boxes, 3000, 6)
 
 
+@pytest.mark.parametrize("name", ["cornell-box2-transmissive", "dragon-spec"])
+def test_device_built_tree_with_reference_ranks_gives_the_reference_image(name, gpu, host_scenes, oracle_scenes):
+    """cpt_build_scene with CPT_SCENE_KEEP_RANKS: the Morton tree built on the GPU, the triangle records keeping the reference
+    tree's tie-break ranks.  The closest hit depends on a tree only through its leaves and the ranks, so hit triangles and
+    distances are the oracle's on the reference tree (tie-prone rays included) and the image is the reference tree's bit
+    for bit, under the reference walk and the culling walk."""
+    import torch
+    from test_gpu_parity import _tie_prone_rays
+    hs = host_scenes(name)
+    orc = oracle_scenes(name)
+    rng = np.random.default_rng(53)
+    boxes, _ = orc.nodes()
+    o1, d1 = random_rays(boxes, rng, 8000)
+    o2, d2 = _tie_prone_rays(orc, rng, 8000)
+    o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    want = orc.trace(o, d)
+    w, h, spp, depth = 64, 48, 4, 6
+    gpu.upload(hs)
+    ref_img = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+    gpu.render_into(ref_img.data_ptr(), gpu.params(w, h, 0, spp, depth))
+    gpu.synchronize()
+    gpu.build(hs, keep_ranks=True)
+    try:
+        for variant in (1, 2):
+            gpu.set_option("extend_variant", variant)
+            tri, t = gpu.extend_rays(o, d)
+            assert np.array_equal(tri, want["prim"]) and np.array_equal(bits(t), bits(want["t"])), variant
+            img = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+            gpu.render_into(img.data_ptr(), gpu.params(w, h, 0, spp, depth))
+            gpu.synchronize()
+            assert torch.equal(img.view(torch.int64), ref_img.view(torch.int64)), variant
+    finally:
+        gpu.set_option("extend_variant", 1)
+
+
 def test_uploaded_tree_without_nested_boxes_runs_the_binary32_variants_as_exact_ones(gpu, host_scenes, oracle):
     """Extend variants 3 and 4 return variant 1's hits only on a tree whose child boxes lie inside their parents'
     boxes and whose leaf boxes are exactly their triangles' bounds.  A caller's tree with tightened leaf boxes (here:
