@@ -466,7 +466,7 @@ def main():
     extras = {}
     for name in names:
         heavy = WORKLOADS[name].get("scaling") == "strong"  # the full-node shapes: tens of seconds per step on two GPUs
-        extras[name] = b.measure(name, 1 if heavy else 2, 1)
+        extras[name] = b.measure(name, 1 if heavy else 2, 1, with_roofline=not heavy)  # their kernels are the headline's and the dragon's
     # The fast modes, beside the numbers above and never instead of them: the same closest hits (so the same image,
     # bit for bit) from a walk that is not the reference's.  3: inner nodes through a conservative binary32 box test,
     # every leaf through the exact test of its own box; 4: the same, nearer child first, boxes beyond the closest hit
