@@ -100,7 +100,7 @@ struct cpt_ctx {
     std::vector<hipEvent_t> events;
 
     int max_blocks = 0;            // grid cap of the grid-stride kernels
-    // Path slots of one batch of the wavefront pipeline, at most (208 bytes each: 7 GB per batch in flight).  Larger
+    // Path slots of one batch of the wavefront pipeline, at most (209 bytes each: 7 GB per batch in flight).  Larger
     // batches render a few per cent faster (shorter launch tails: dragon +6 % at 2^27), but a process that allocates
     // tens of GB and exits leaves the driver seconds of reclaiming that the next process waits for, which matters
     // more to a command line that renders in half a second; long-lived callers raise it with cpt_set_option.
@@ -772,6 +772,7 @@ static void carve_paths(cpt_ctx::Lane& l, void* base, size_t slots) {
     uint32_t* u = (uint32_t*)p;
     l.R[0].slot = u; u += slots;
     l.R[1].slot = u; u += slots;
+    l.C.lit = (uint8_t*)u;
     l.path_capacity = slots;
 }
 

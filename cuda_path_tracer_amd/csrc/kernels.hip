@@ -137,7 +137,9 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_generate(DScene sc, DParams P, Ra
             v.x = o.z; v.y = d.x; CPT_NT_STORE(out.ozdx[p], v);
             v.x = d.y; v.y = d.z; CPT_NT_STORE(out.dyz[p], v);
         }
-        col.cx[slot] = 0.0; col.cy[slot] = 0.0; col.cz[slot] = 0.0;
+        // the path has gathered nothing yet: one byte says so (the 24 bytes of radiance are written by the first emitter the
+        // path meets and read by k_resolve only if there was one -- most paths of most scenes never meet one)
+        col.lit[slot] = 0;
     }
 }
 
@@ -780,7 +782,12 @@ __global__ void __launch_bounds__(CPT_SHADE_BLOCK, CPT_SHADE_MIN_WAVES) k_shade(
                 dvec3 emitted;
                 int lobe = choose_lobe(sc, P, pixel, sample, bounce, tri, s.atten, emitted);
                 if (emitted.x != 0.0 || emitted.y != 0.0 || emitted.z != 0.0) {  // adding zero changes nothing: skip the round trip
-                    col.cx[slot] += emitted.x; col.cy[slot] += emitted.y; col.cz[slot] += emitted.z;
+                    if (!FIRST && col.lit[slot]) {
+                        col.cx[slot] += emitted.x; col.cy[slot] += emitted.y; col.cz[slot] += emitted.z;
+                    } else {  // the path's first emitter: 0 + e = e, stored without reading what the slot held before
+                        col.cx[slot] = emitted.x; col.cy[slot] = emitted.y; col.cz[slot] = emitted.z;
+                        col.lit[slot] = 1;
+                    }
                 }
                 if (lobe != CPT_LOBE_NONE) {
                     scatter(lobe, sc, P, pixel, sample, bounce, t, tri, s);
@@ -808,7 +815,9 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_resolve(DParams P, Radiance col, 
         dvec3 sum = dv(px[0], px[1], px[2]);
         for (int k = 0; k < batch_n; ++k) {
             size_t slot = (size_t)k * P.n_pix_slots + ps;
-            sum = sum + dv(col.cx[slot], col.cy[slot], col.cz[slot]);
+            // a path that met no emitter has radiance +0, and adding it would change nothing (a sum is never -0: it starts
+            // from the caller's buffer and only ever receives finite throughput times ke)
+            if (col.lit[slot]) sum = sum + dv(col.cx[slot], col.cy[slot], col.cz[slot]);
         }
         px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
     }

@@ -117,9 +117,10 @@ struct HitBuf {             // extend -> shade, indexed by queue position
     HitRec* rec;
 };
 struct Radiance {           // radiance gathered per path, indexed by slot; touched only at emitters
-    double *cx, *cy, *cz;
+    double *cx, *cy, *cz;   // meaningful only where `lit` is set: generate clears the flag, not the 24 bytes of radiance
+    uint8_t* lit;           // 1 once an emitter has contributed to the slot's path
 };
-#define CPT_SLOT_BYTES (2 * CPT_STREAM_BYTES + 16 + 24)  // device bytes per path slot of a batch: two streams, hit record, radiance
+#define CPT_SLOT_BYTES (2 * CPT_STREAM_BYTES + 16 + 24 + 1)  // device bytes per path slot of a batch: two streams, hit record, radiance, its flag
 
 // traversal stack of the persistent-wave extend kernel: entries in LDS, and the deepest tree it accepts
 #ifndef CPT_PW_STACK_LDS_HOST

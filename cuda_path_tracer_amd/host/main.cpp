@@ -52,7 +52,7 @@ void usage(const char* prog, const Cli& c) {
               << "  --rr        Russian roulette\n"
               << "  --seed <#>  random seed (default 1984)\n"
               << "  --device <#> GPU ordinal (default 0)\n"
-              << "  --batch <#>  path slots per batch (208 bytes each, two batches in flight; default 2^25, at most 2^28)\n"
+              << "  --batch <#>  path slots per batch (209 bytes each, two batches in flight; default 2^25, at most 2^28)\n"
               << "  --devices <#,#,...>  split the samples over these GPUs (one host thread and context each)\n"
               << "  --device-bvh        build the BVH on the GPU (a Morton-order tree, not the reference's)\n"
               << "  --fast              fast mode: surface-area tree with the reference's tie-break ranks (same image, bit for bit,\n"

@@ -229,7 +229,7 @@ int cpt_render(cpt_ctx* ctx, const cpt_render_params* params, double* d_accum);
  * library's device code, so the call makes no hipMalloc / hipFree and creates no events or streams.  It has no
  * counterpart in the reference (whose render path allocates per object, src/gpu/GPUManaged.cuh:19-24).
  * Limits: one sample of the tile window must fit, i.e.
- *   2 * 2 KB * (depth + 2)  +  4 KB * CUs * max(0, tree height - 14)  +  208 B * (pixels of the window, in whole 8x8 tiles)
+ *   2 * 2 KB * (depth + 2)  +  4 KB * CUs * max(0, tree height - 14)  +  209 B * (pixels of the window, in whole 8x8 tiles)
  * must not exceed CPT_NOALLOC_SCRATCH_BYTES (a 512x512 image at any accepted tree height does; a 1024x1024 image is
  * rendered as four tile windows); otherwise CPT_ELIMIT.  Samples are rendered in as large batches as fit, one batch
  * at a time on the context's stream; instrumentation settings are ignored.  Every context on a GPU shares that

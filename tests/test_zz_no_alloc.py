@@ -44,8 +44,8 @@ def test_noalloc_refuses_what_does_not_fit(gpu_scene):
     from cuda_path_tracer_amd import CptError
     from cuda_path_tracer_amd._capi import NOALLOC_SCRATCH_BYTES
     g = gpu_scene("cornell-box2")
-    w = h = 1024  # 1 048 576 path slots of 208 bytes per sample: beyond the 128 MiB array
-    assert w * h * 208 > NOALLOC_SCRATCH_BYTES
+    w = h = 1024  # 1 048 576 path slots of 209 bytes per sample: beyond the 128 MiB array
+    assert w * h * 209 > NOALLOC_SCRATCH_BYTES
     acc = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
     with pytest.raises(CptError, match="static scratch"):
         g.render_into_noalloc(acc.data_ptr(), g.params(w, h, 0, 1, 3))
