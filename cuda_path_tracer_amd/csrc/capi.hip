@@ -57,6 +57,11 @@ struct cpt_ctx {
 
     void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_nodes32 = nullptr;
     void* d_nodes_pw = nullptr;  // node records with children in stack-minimal order (or d_nodes itself)
+    // d_nodes_pw and d_tris restated for rays that start at the camera's eye (launch_eye_records), allocated with the scene
+    // and filled in by the first pin-hole render that uses them; eye_of is the eye they were made for
+    void *d_nodes_eye = nullptr, *d_tris_eye = nullptr;
+    double eye_of[3] = {0, 0, 0};
+    bool eye_current = false;
     // Whether the tree on the device has the properties the binary32 extend variants rely on: every child box lies inside
     // its parent's box and every leaf box is exactly the bounds of its triangle's vertices (then a leaf's box passing the
     // exact test implies every box above it passes, and the root's two child boxes bound every plane of the tree).  The
@@ -109,6 +114,7 @@ struct cpt_ctx {
     int pw_chunk = 0;              // rays a persistent wave claims per atomic; 0: chosen from the scene, see chunk_for
     int pw_refill = 12, pw_leaf_go = 0, pw_full_go = 1;  // pw_leaf_go 0: chosen from the walk, see leaf_go_for
     int pw_box_repeat = 0;  // 0: chosen from the tree, see box_repeat_for
+    int pw_eye = 1;         // first rays of a pin-hole render through the shared-origin instance of the persistent extend kernel
     bool caller_ranks = false;  // the scene in place was uploaded with CPT_SCENE_KEEP_RANKS (a tree other than the reference's)
     int extend_variant = 1;        // 0: one ray per thread; 1: persistent waves with refill; 2: as 1, nearest-first with culling
 };
@@ -144,7 +150,10 @@ static void free_scene(cpt_ctx* c) {
     if (c->d_tris) (void)hipFree(c->d_tris);
     if (c->d_shade) (void)hipFree(c->d_shade);
     if (c->d_nodes32) (void)hipFree(c->d_nodes32);
-    c->d_nodes = c->d_tris = c->d_shade = c->d_nodes32 = c->d_nodes_pw = nullptr;
+    if (c->d_nodes_eye) (void)hipFree(c->d_nodes_eye);
+    if (c->d_tris_eye) (void)hipFree(c->d_tris_eye);
+    c->d_nodes = c->d_tris = c->d_shade = c->d_nodes32 = c->d_nodes_pw = c->d_nodes_eye = c->d_tris_eye = nullptr;
+    c->eye_current = false;
     c->has_scene = false;
     c->tri_ext.clear();  // the index translation belongs to the scene that is gone
     c->tri_int.clear();
@@ -266,6 +275,9 @@ int cpt_set_option(cpt_ctx* c, const char* key, long long value) {
     } else if (!strcmp(key, "pw_box_repeat")) {
         if (value != 0 && value != 2 && value != 3) return fail(c, CPT_EINVAL, "pw_box_repeat must be 0 (automatic), 2 or 3");
         c->pw_box_repeat = (int)value;
+    } else if (!strcmp(key, "pw_eye")) {
+        if (value != 0 && value != 1) return fail(c, CPT_EINVAL, "pw_eye must be 0 or 1");
+        c->pw_eye = (int)value;
     } else if (!strcmp(key, "pw_leaf_go")) {
         if (value < 0 || value > 64) return fail(c, CPT_EINVAL, "pw_leaf_go must be in [0, 64]");
         c->pw_leaf_go = (int)value;
@@ -514,8 +526,14 @@ static int upload_shading(cpt_ctx* c, const cpt_scene_desc* s) {
 }
 
 // Binary32 copies of the node records (boxes rounded outwards) for the extend variants that test inner nodes in
-// binary32, derived on the device from the records in place.
+// binary32, derived on the device from the records in place.  Also (re)allocates the shared-origin copies, whose
+// contents wait for a render to name the eye: every scene-changing call ends here.
 static int make_nodes32(cpt_ctx* c, int n_nodes) {
+    c->eye_current = false;
+    if (!c->d_nodes_eye) HIP_TRY(c, hipMalloc(&c->d_nodes_eye, sizeof(cpt_node) * (size_t)std::max(n_nodes, 1)));
+    if (!c->d_tris_eye) HIP_TRY(c, hipMalloc(&c->d_tris_eye, sizeof(cpt_tri) * (size_t)std::max(c->sc.n_tris, 1)));
+    c->sc.nodes_eye = (const cpt_node*)c->d_nodes_eye;
+    c->sc.tris_eye = (const cpt_tri*)c->d_tris_eye;
     if (c->d_nodes32) { (void)hipFree(c->d_nodes32); c->d_nodes32 = nullptr; }
     HIP_TRY(c, hipMalloc(&c->d_nodes32, 64 * (size_t)std::max(n_nodes, 1)));
     launch_nodes32(c->stream, (const cpt_node*)c->d_nodes_pw, n_nodes, c->d_nodes32);
@@ -872,6 +890,17 @@ static int run_wavefront(cpt_ctx* c, const DParams& P, LaunchCfg L, cpt_ctx::Lan
     int rc;
     const size_t n_ev = 2 * (size_t)(P.depth + 1) + 3;
     if (timed) { rc = need_events(c, n_ev); if (rc) return rc; }
+    // First rays of a pin-hole render all start at the eye: their extend launch takes the records restated for that origin,
+    // which are brought up to date here when the scene or the eye has changed since they were made.
+    const double* eye = c->sc.cam.eye;
+    const bool use_eye = c->pw_eye && !P.dof && c->extend_variant >= 1 && !L.pw_f32 && c->sc.n_nodes > 0 &&
+                         std::fabs(eye[0]) < 1e300 && std::fabs(eye[1]) < 1e300 && std::fabs(eye[2]) < 1e300;
+    if (use_eye && !(c->eye_current && eye[0] == c->eye_of[0] && eye[1] == c->eye_of[1] && eye[2] == c->eye_of[2])) {
+        launch_eye_records(st[0], c->sc, (cpt_node*)c->d_nodes_eye, (cpt_tri*)c->d_tris_eye);
+        HIP_TRY(c, hipGetLastError());
+        for (int k = 0; k < 3; ++k) c->eye_of[k] = eye[k];
+        c->eye_current = true;
+    }
     if (n_lanes > 1) {  // the other lanes start after whatever the caller queued before this render
         HIP_TRY(c, hipEventRecord(c->ev_fork, st[0]));
         for (int k = 1; k < n_lanes; ++k) HIP_TRY(c, hipStreamWaitEvent(st[k], c->ev_fork, 0));
@@ -895,6 +924,7 @@ static int run_wavefront(cpt_ctx* c, const DParams& P, LaunchCfg L, cpt_ctx::Lan
         for (int b = 0; b <= P.depth; ++b) {
             const RayStream& in = ln.R[b & 1];
             uint32_t* count_in = ln.d_counters + (size_t)b * CPT_PW_CURSOR_WORDS;
+            L.pw_eye = b == 0 && use_eye;
             if (c->extend_variant >= 1) launch_extend_pw(L, c->sc, in, ln.H, count_in, cap, cursors + (size_t)b * CPT_PW_CURSOR_WORDS, ln.d_spill, work, ExtendObserve{nullptr, nullptr, 0});
             else launch_extend(L, c->sc, in, ln.H, count_in, cap, slots, work, ExtendObserve{nullptr, nullptr, 0});
             if (timed) HIP_TRY(c, hipEventRecord(c->events[ev++], L.stream));
@@ -944,7 +974,7 @@ static int leaf_go_for(const cpt_ctx* c) { return c->pw_leaf_go > 0 ? c->pw_leaf
 static int box_repeat_for(const cpt_ctx* c) { return c->pw_box_repeat ? c->pw_box_repeat : (c->caller_ranks ? 2 : 3); }
 
 static LaunchCfg launch_cfg(const cpt_ctx* c) {
-    return LaunchCfg{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_mode(c), variant_cull(c), variant_f32(c), c->pw_full_go, leaf_go_for(c), box_repeat_for(c)};
+    return LaunchCfg{c->stream, c->max_blocks, c->pw_blocks, chunk_for(c), c->pw_refill, scene_mode(c), variant_cull(c), variant_f32(c), c->pw_full_go, leaf_go_for(c), box_repeat_for(c), 0};
 }
 
 int cpt_render(cpt_ctx* c, const cpt_render_params* p, double* d_accum) {

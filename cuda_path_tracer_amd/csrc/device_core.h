@@ -140,11 +140,13 @@ __device__ __forceinline__ bool slab_filtered(double lx, double ly, double lz, d
 
 // Ray/triangle test (reference: src/gpu/GPUTrimesh.cuh:59-113): plane hit, back-face cull unless
 // the material is reflective/transmissive, t >= 0, three edge tests.  Returns t through t_out.
+// The plane term of the test, -dot(o - a, n) (src/gpu/GPUTrimesh.cuh:62): a function of the ray's origin and the triangle alone.
+__device__ __forceinline__ double tri_numerator(const dvec3& o, const dvec3& a, const dvec3& n) { return -dot(o - a, n); }
+// `numerator` is tri_numerator(o, a, n), worked out by the caller: per test, or once per triangle for rays that share an origin.
 __device__ __forceinline__ bool tri_hit_regs(double2 q0, double2 q1, double2 q2, double2 q3, double2 q4, double2 q5,
-                                             uint32_t flags, const dvec3& o, const dvec3& d, double& t_out) {
+                                             uint32_t flags, double numerator, const dvec3& o, const dvec3& d, double& t_out) {
     dvec3 a = dv(q0.x, q0.y, q1.x), b = dv(q1.y, q2.x, q2.y), c = dv(q3.x, q3.y, q4.x), n = dv(q4.y, q5.x, q5.y);
     bool recur = (flags & CPT_TRI_RECUR) != 0;
-    double numerator = -dot(o - a, n);
     double denominator = dot(d, n);
     if (denominator >= 0) {
         if (!recur || denominator == 0) return false;
@@ -157,6 +159,10 @@ __device__ __forceinline__ bool tri_hit_regs(double2 q0, double2 q1, double2 q2,
     bool res = dot(cross(vba, vpa), n) >= 0 && dot(cross(vcb, vpb), n) >= 0 && dot(cross(vac, vpc), n) >= 0;
     t_out = t;
     return res;
+}
+__device__ __forceinline__ bool tri_hit_regs(double2 q0, double2 q1, double2 q2, double2 q3, double2 q4, double2 q5,
+                                             uint32_t flags, const dvec3& o, const dvec3& d, double& t_out) {
+    return tri_hit_regs(q0, q1, q2, q3, q4, q5, flags, tri_numerator(o, dv(q0.x, q0.y, q1.x), dv(q4.y, q5.x, q5.y)), o, d, t_out);
 }
 __device__ __forceinline__ bool tri_hit(const cpt_tri* __restrict__ tp, const dvec3& o, const dvec3& d,
                                         double& t_out) {

@@ -419,6 +419,37 @@ __device__ __forceinline__ void slab32_pair(v2f lox, v2f loy, v2f loz, v2f hix, 
 #undef CPT_SLAB32
 }
 
+// ---- records for rays that share an origin ----------------------------------------------------------
+// Every first ray of a pin-hole render starts at the camera's eye.  The slab test's first operation on a box plane is
+// plane - origin (reference: src/gpu/GPUbb.cuh:33-34) and the triangle test's plane term is -dot(origin - a, n)
+// (src/gpu/GPUTrimesh.cuh:62): with the origin fixed both are properties of the record, so they are worked out here once
+// per camera, with the very operations the per-ray code uses, and the EYE instance of the persistent kernel reads them
+// instead of redoing them at every node step and triangle test -- 12 of a node step's subtractions and 8 of a triangle
+// test's operations, with bit-identical results.
+// Node records keep their layout.  Triangle records keep vertices and normal; bytes 96..111 become
+// (test_rank, flags, plane term): the material index is not needed by the walk.
+__global__ void __launch_bounds__(CPT_BLOCK) k_eye_records(const cpt_node* __restrict__ nodes, int n_nodes, const cpt_tri* __restrict__ tris,
+                                                           int n_tris, dvec3 eye, cpt_node* __restrict__ nodes_out, cpt_tri* __restrict__ tris_out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes + n_tris; i += gridDim.x * blockDim.x) {
+        if (i < n_nodes) {
+            cpt_node r = nodes[i];
+            r.lbox[0] = r.lbox[0] - eye.x; r.lbox[1] = r.lbox[1] - eye.y; r.lbox[2] = r.lbox[2] - eye.z;
+            r.lbox[3] = r.lbox[3] - eye.x; r.lbox[4] = r.lbox[4] - eye.y; r.lbox[5] = r.lbox[5] - eye.z;
+            r.rbox[0] = r.rbox[0] - eye.x; r.rbox[1] = r.rbox[1] - eye.y; r.rbox[2] = r.rbox[2] - eye.z;
+            r.rbox[3] = r.rbox[3] - eye.x; r.rbox[4] = r.rbox[4] - eye.y; r.rbox[5] = r.rbox[5] - eye.z;
+            nodes_out[i] = r;
+        } else {
+            const int k = i - n_nodes;
+            cpt_tri r = tris[k];
+            const double num = tri_numerator(eye, dv(r.a[0], r.a[1], r.a[2]), dv(r.n[0], r.n[1], r.n[2]));
+            r.material = (int32_t)r.test_rank;
+            double2* q = (double2*)&r;
+            q[6].y = num;
+            tris_out[k] = r;
+        }
+    }
+}
+
 //
 // CULL selects the fast mode: of two child boxes that are both hit the nearer one is walked first, and
 // a box the ray enters beyond the closest hit found so far (with a relative margin of 1e-6) is not
@@ -431,12 +462,19 @@ __device__ __forceinline__ void slab32_pair(v2f lox, v2f loy, v2f loz, v2f hix, 
 // stack, so the loop has no vector-memory record or spill path and none of the waits that come with
 // them; the only loads left are the rays.
 // F32: inner nodes through the conservative binary32 test, leaves through the exact test of their own box (see above).
-template <bool COUNT, bool CULL, int MODE, bool F32, int REPS>
+// EYE: every live ray of the stream starts at `eye` (the first rays of a pin-hole render) and the records come from
+// k_eye_records: the origin lives in scalar registers, is not loaded per ray, and the box and triangle tests skip the
+// operations the records already contain.  A slot without a path (origin 1e300, see k_generate) is retired at once with
+// the counts its walk would have had: one node step through the exact test, no triangle.
+template <bool COUNT, bool CULL, int MODE, bool F32, int REPS, bool EYE>
 __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStream in, HitBuf hit,
                                                               const uint32_t* __restrict__ counter, uint32_t* cursor, uint32_t cap,
                                                               uint32_t chunk, uint32_t refill_at, uint32_t leaf_go, uint32_t full_go, uint32_t* spill, unsigned long long* work,
-                                                              ExtendObserve obs) {
+                                                              ExtendObserve obs, dvec3 eye) {
+    static_assert(!(F32 && EYE), "the shared-origin records exist for the exact variants only");
     constexpr bool RESIDENT = MODE == 2, LDS_STACK = MODE >= 1;
+    const void* const node_recs = EYE ? (const void*)sc.nodes_eye : (const void*)sc.nodes_pw;
+    const void* const tri_recs = EYE ? (const void*)sc.tris_eye : (const void*)sc.tris;
     typedef PwPlan<F32> Plan;
     constexpr int kStackLds = Plan::STACK_LDS, kLeafCap = Plan::LEAF_CAP;
     constexpr int kPlaneBytes = F32 ? 0 : Plan::PLANE_BYTES;  // 0: whole records with rotated pieces (fetch_record)
@@ -482,8 +520,8 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     } else {
         for (int i = (int)threadIdx.x; i < (cached_nodes + cached_tris) * 8; i += CPT_PW_THREADS) {
             int r = i >> 3, c = i & 7;
-            const unsigned char* src = r < cached_nodes ? (const unsigned char*)sc.nodes_pw + (size_t)r * 128
-                                                        : (const unsigned char*)sc.tris + (size_t)(r - cached_nodes) * 128;
+            const unsigned char* src = r < cached_nodes ? (const unsigned char*)node_recs + (size_t)r * 128
+                                                        : (const unsigned char*)tri_recs + (size_t)(r - cached_nodes) * 128;
             if (c < 7) *(double2*)(s_cache + (size_t)c * Plan::PLANE_BYTES + (size_t)r * 16) = *(const double2*)(src + c * 16);  // planar, see planar_record
         }
     }
@@ -518,7 +556,7 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     bool has_ray = false;
     int node = -1, sp = 0;
     uint32_t pos = 0;  // stream position of this lane's ray
-    dvec3 o = dv(0, 0, 0), d = dv(0, 0, 1);
+    dvec3 o = EYE ? eye : dv(0, 0, 0), d = dv(0, 0, 1);
     SlabRay sr = slab_prepare(o, dv(1, 1, 1));
     Ray32 q32 = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double best_t = -1.0;
@@ -551,7 +589,14 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
             uint32_t mine = (uint32_t)__popcll(idle & lanes_below);
             if (!has_ray && mine < take) {
                 pos = chunk_pos + mine;  // idle lanes take consecutive positions: one contiguous run per refill
-                load_ray_geometry(in, pos, o, d);
+                bool no_path = false;
+                if (EYE) {
+                    const cpt_v2d b = CPT_NT_LOAD(in.ozdx[pos]), cc = CPT_NT_LOAD(in.dyz[pos]);
+                    d = dv(b.y, cc.x, cc.y);
+                    no_path = b.x == 1e300;
+                } else {
+                    load_ray_geometry(in, pos, o, d);
+                }
                 sr = slab_prepare(o, d);
                 if (F32) q32 = ray32_prepare(o, sr, scene_extent);
                 best_t = -1.0;
@@ -562,7 +607,10 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 node_top = node_base;
                 leaf_top = leaf_base;
                 has_ray = true;
-                if (sc.n_nodes > 0) {
+                if (EYE && no_path) {
+                    node = -1;
+                    if (COUNT) { steps++; exact++; }
+                } else if (sc.n_nodes > 0) {
                     node = 0;
                 } else {  // one-triangle scene
                     node = -1;
@@ -604,16 +652,17 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                     enter_l = (double)el;
                     enter_r = (double)er;
                 } else {
-                    const Rec7 r = fetch_record<RESIDENT, kPlaneBytes>(sc.nodes_pw, cache, 0, cached_nodes, node);
+                    const Rec7 r = fetch_record<RESIDENT, kPlaneBytes>(node_recs, cache, 0, cached_nodes, node);
                     refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));
                     ids = make_int2(__double2loint(r.p6.y), __double2hiint(r.p6.y));
                     bool sure_l, sure_r;
-                    hl = slab_filtered(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, sr, sure_l, enter_l);
-                    hr = slab_filtered(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, sr, sure_r, enter_r);
+                    const dvec3 box_o = EYE ? dv(0, 0, 0) : o;  // what the tests subtract from a plane: nothing when the record already has (x - 0 is x)
+                    hl = slab_filtered(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, box_o, sr, sure_l, enter_l);
+                    hr = slab_filtered(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, box_o, sr, sure_r, enter_r);
                     if (sr.exact_only || !(sure_l && sure_r)) {
                         if (COUNT) exact++;
-                        hl = slab_hit(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, o, d, enter_l);
-                        hr = slab_hit(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, o, d, enter_r);
+                        hl = slab_hit(r.p0.x, r.p0.y, r.p1.x, r.p1.y, r.p2.x, r.p2.y, box_o, d, enter_l);
+                        hr = slab_hit(r.p3.x, r.p3.y, r.p4.x, r.p4.y, r.p5.x, r.p5.y, box_o, d, enter_r);
                     }
                 }
                 if (COUNT) {  // both child boxes have been tested (reference: src/gpu/GPUBVH.cu:56-57), whatever the walk does next
@@ -683,8 +732,9 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 if (leaf_top != leaf_base) {
                     leaf_top -= CPT_WAVE;
                     int tri = (int)~*leaf_top;
-                    Rec7 q = fetch_record<RESIDENT, kPlaneBytes>(sc.tris, cache, tri_first, cached_tris, tri);
-                    uint32_t flags = (uint32_t)__double2hiint(q.p6.x), rank = (uint32_t)__double2loint(q.p6.y);
+                    Rec7 q = fetch_record<RESIDENT, kPlaneBytes>(tri_recs, cache, tri_first, cached_tris, tri);
+                    const uint32_t flags = (uint32_t)__double2hiint(q.p6.x);
+                    const uint32_t rank = (uint32_t)__double2loint(EYE ? q.p6.x : q.p6.y);  // see k_eye_records
                     bool gate = true;
                     if (F32 && sc.n_nodes > 0) {  // (a one-triangle scene has no boxes at all) the exact test of the leaf's own box: the bounds of the three vertices (reference: src/scene/bvh.cpp:128-146)
                         const double lx = fmin(fmin(q.p0.x, q.p1.y), q.p3.x), hx = fmax(fmax(q.p0.x, q.p1.y), q.p3.x);
@@ -702,7 +752,8 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                     double t;
                     if (gate) {
                         if (COUNT) tris++;
-                        if (tri_hit_regs(q.p0, q.p1, q.p2, q.p3, q.p4, q.p5, flags, o, d, t)) {
+                        const double numerator = EYE ? q.p6.y : tri_numerator(o, dv(q.p0.x, q.p0.y, q.p1.x), dv(q.p4.y, q.p5.x, q.p5.y));
+                        if (tri_hit_regs(q.p0, q.p1, q.p2, q.p3, q.p4, q.p5, flags, numerator, o, d, t)) {
                             if (best_t < 0 || t < best_t || (t == best_t && rank < best_rank)) { best_t = t; best_tri = tri; best_rank = rank; }
                         }
                     }
@@ -977,6 +1028,11 @@ void launch_nodes32(hipStream_t st, const cpt_node* d_nodes, int n_nodes, void* 
     int g = (n_nodes + CPT_BLOCK - 1) / CPT_BLOCK;
     hipLaunchKernelGGL(k_nodes32, dim3(g > 4096 ? 4096 : g), dim3(CPT_BLOCK), 0, st, d_nodes, n_nodes, (Node32*)d_nodes32);
 }
+void launch_eye_records(hipStream_t st, const DScene& sc, cpt_node* d_nodes_eye, cpt_tri* d_tris_eye) {
+    const int n = sc.n_nodes + sc.n_tris, g = (n + CPT_BLOCK - 1) / CPT_BLOCK;
+    hipLaunchKernelGGL(k_eye_records, dim3(g > 8192 ? 8192 : g), dim3(CPT_BLOCK), 0, st, sc.nodes_pw, sc.n_nodes, sc.tris, sc.n_tris,
+                       dv(sc.cam.eye[0], sc.cam.eye[1], sc.cam.eye[2]), d_nodes_eye, d_tris_eye);
+}
 void launch_dense_counts(const LaunchCfg& L, uint32_t* counts, uint32_t n, uint32_t cap) {
     hipLaunchKernelGGL(k_dense_counts, dim3(1), dim3(64), 0, L.stream, counts, n, cap);
 }
@@ -989,13 +1045,18 @@ void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, co
 void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
                       uint32_t cap, uint32_t* cursor, uint32_t* spill, unsigned long long* work, const ExtendObserve& obs) {
     int g = L.pw_blocks;
-#define CPT_PW_LAUNCH(COUNT, CULL, RES, F32, REPS)                                                                                  \
-    hipLaunchKernelGGL((k_extend_pw<COUNT, CULL, RES, F32, REPS>), dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, \
+    const dvec3 eye = dv(sc.cam.eye[0], sc.cam.eye[1], sc.cam.eye[2]);
+    const bool use_eye = L.pw_eye && !L.pw_f32;
+#define CPT_PW_LAUNCH(COUNT, CULL, RES, F32, REPS, EYE)                                                                                  \
+    hipLaunchKernelGGL((k_extend_pw<COUNT, CULL, RES, F32, REPS, EYE>), dim3(g), dim3(CPT_PW_THREADS), 0, L.stream, sc, in, hit, counter, \
                        cursor, cap, (uint32_t)L.pw_chunk, (uint32_t)L.pw_refill, (uint32_t)L.pw_leaf_go,                       \
-                       (uint32_t)L.pw_full_go, spill, work, obs)
+                       (uint32_t)L.pw_full_go, spill, work, obs, eye)
+#define CPT_PW_LAUNCH_EYE(COUNT, CULL, MODE, F32, REPS)                                   \
+    if (!F32 && use_eye) CPT_PW_LAUNCH(COUNT, CULL, MODE, F32, REPS, (!F32));                 \
+    else CPT_PW_LAUNCH(COUNT, CULL, MODE, F32, REPS, false)
 #define CPT_PW_LAUNCH_REPS(COUNT, CULL, MODE, F32)                                   \
-    if (L.pw_box_repeat == 2) CPT_PW_LAUNCH(COUNT, CULL, MODE, F32, 2);                 \
-    else CPT_PW_LAUNCH(COUNT, CULL, MODE, F32, 3)
+    if (L.pw_box_repeat == 2) { CPT_PW_LAUNCH_EYE(COUNT, CULL, MODE, F32, 2); }                 \
+    else { CPT_PW_LAUNCH_EYE(COUNT, CULL, MODE, F32, 3); }
 #define CPT_PW_LAUNCH_MODE(COUNT, CULL, F32)                                            \
     switch (L.pw_mode) {                                                                \
         case 2: CPT_PW_LAUNCH_REPS(COUNT, CULL, 2, F32); break;                         \
@@ -1015,6 +1076,7 @@ void launch_extend_pw(const LaunchCfg& L, const DScene& sc, const RayStream& in,
     }
 #undef CPT_PW_LAUNCH_MODE
 #undef CPT_PW_LAUNCH_REPS
+#undef CPT_PW_LAUNCH_EYE
 #undef CPT_PW_LAUNCH
 }
 void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& in, const HitBuf& hit,

@@ -60,6 +60,10 @@ struct DScene {
     const cpt_tri* __restrict__ tris;       // intersection records (extend)
     const ShadeRec* __restrict__ shade;     // shading records (shade), one per triangle
     const void* __restrict__ nodes32;       // 64-byte binary32 copies of the node records, boxes rounded outwards (extend variants 3 and 4)
+    // nodes_pw and tris restated for rays that start at the pin-hole camera's eye (k_eye_records): every box plane with the
+    // eye's coordinate already subtracted, every triangle with its plane term for that origin
+    const cpt_node* __restrict__ nodes_eye;
+    const cpt_tri* __restrict__ tris_eye;
     cpt_camera cam;
     int n_nodes, n_tris;
 };
@@ -168,11 +172,13 @@ struct LaunchCfg {
     int pw_full_go;  // ... or when at least this many lanes cannot expand a node because their parked-leaf list is full
     int pw_leaf_go;  // a wave runs its triangle phase when at least this many lanes have a parked leaf
     int pw_box_repeat; // node expansions per lane between two looks at the triangle phase: 2 or 3 (compiled instances)
+    int pw_eye;        // 1: every live ray of the stream starts at sc.cam.eye and sc.nodes_eye / sc.tris_eye are current (exact variants only)
 };
 
 void launch_generate(const LaunchCfg& L, const DScene& sc, const DParams& P, const RayStream& out, const Radiance& col,
                      int batch_s0, int batch_n);
 void launch_nodes32(hipStream_t st, const cpt_node* d_nodes, int n_nodes, void* d_nodes32);
+void launch_eye_records(hipStream_t st, const DScene& sc, cpt_node* d_nodes_eye, cpt_tri* d_tris_eye);
 void launch_dense_counts(const LaunchCfg& L, uint32_t* counts, uint32_t n, uint32_t cap);
 void launch_extend(const LaunchCfg& L, const DScene& sc, const RayStream& in, const HitBuf& hit, const uint32_t* counter,
                    uint32_t cap, long long max_entries, unsigned long long* work, const ExtendObserve& obs);

@@ -178,6 +178,11 @@ int cpt_set_stream(cpt_ctx* ctx, void* hip_stream);
  * atomic, 0 = chosen from the scene size),
  * "pw_box_repeat" (node expansions per lane between two looks at the triangle phase: 3 or 2; 0 = 3, or 2 for a tree
  * uploaded with CPT_SCENE_KEEP_RANKS, whose walks are shorter),
+ * "pw_eye" (1, default: the first rays of a pin-hole render, which all start at the camera's eye, are intersected by an
+ * instance of that kernel whose node and triangle records already contain the terms that depend on the origin alone --
+ * plane - eye, reference src/gpu/GPUbb.cuh:33-34, and -dot(eye - a, n), src/gpu/GPUTrimesh.cuh:62 -- worked out once per
+ * camera with the same operations; same hits, same visit sets, a fifth less arithmetic per node step of those rays, and
+ * one more copy of the node and triangle records on the device; 0: every bounce through the general instance),
  * "pw_refill" / "pw_leaf_go" / "pw_full_go" (a wave of that kernel refills when this many lanes are
  * idle / runs its triangle pass when this many lanes have a parked leaf, 0 = 32 for the reference walk and 16 for the
  * culling walks / or when this many lanes cannot go on because their parked-leaf list is full). */

@@ -567,6 +567,48 @@ def test_every_pipeline_variant_gives_the_same_image(gpu_scene):
         assert np.array_equal(bits(images[0]), bits(im))
 
 
+@pytest.mark.parametrize("name", ["cornell-box2-transmissive", "teapot-trans", "dragon-spec"])
+def test_shared_origin_instance_of_the_first_bounce_changes_nothing(name, gpu_scene):
+    """First rays of a pin-hole render go through the instance of the persistent extend kernel whose records already
+    contain `plane - eye` and the triangles' plane terms for the eye (reference operations: src/gpu/GPUbb.cuh:33-34,
+    src/gpu/GPUTrimesh.cuh:62).  With it and without it: the same accumulation buffer bit for bit and, on the reference
+    walk, the same work counters -- on an image whose sides are not multiples of 8, so that slots without a path
+    take the instance's short cut."""
+    import torch
+    g = gpu_scene(name)
+    w, h, spp, depth = 61, 45, 5, 6
+    try:
+        for variant in (1, 2):
+            for repeat in (2, 3):
+                g.set_option("extend_variant", variant)
+                g.set_option("pw_box_repeat", repeat)
+                got = []
+                for eye in (1, 0):
+                    g.set_option("pw_eye", eye)
+                    g.reset_stats()
+                    g.set_instrumentation(False, True)
+                    acc = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+                    g.render_into(acc.data_ptr(), g.params(w, h, 0, spp, depth))
+                    g.synchronize()
+                    st = g.stats()
+                    g.set_instrumentation(False, False)
+                    # and once more without the counting instance
+                    acc2 = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+                    g.render_into(acc2.data_ptr(), g.params(w, h, 0, spp, depth))
+                    g.synchronize()
+                    assert np.array_equal(bits(acc.cpu().numpy()), bits(acc2.cpu().numpy()))
+                    got.append((acc.cpu().numpy(), st))
+                assert np.array_equal(bits(got[0][0]), bits(got[1][0])), (variant, repeat)
+                assert got[0][0].any()
+                if variant == 1:  # the culling walk's counts depend on when a wave runs its triangle passes
+                    for k in ("paths", "segments", "hits", "node_steps", "tri_tests", "exact_node_steps"):
+                        assert got[0][1][k] == got[1][1][k], (variant, repeat, k, got[0][1][k], got[1][1][k])
+    finally:
+        g.set_option("extend_variant", 1)
+        g.set_option("pw_box_repeat", 0)
+        g.set_option("pw_eye", 1)
+
+
 @pytest.mark.parametrize("name", ["cornell-box2-transmissive", "teapot-trans", "dragon-spec", "3-dragon-spec"])
 def test_fast_tree_returns_the_reference_hits_and_the_same_image(name, gpu, host_scenes, oracle_scenes, oracle):
     """The fast mode's tree (surface-area build over the same triangles, the reference tree's tie-break ranks in the
