@@ -80,7 +80,7 @@ MODE_MEGAKERNEL = 1
 # every symbol include/cpt_amd.h declares
 AMD_SYMBOLS = [
     "cpt_create", "cpt_destroy", "cpt_last_error", "cpt_set_stream", "cpt_set_option", "cpt_set_instrumentation",
-    "cpt_upload_scene", "cpt_build_scene", "cpt_refit_scene", "cpt_download_tree", "cpt_render", "cpt_render_noalloc", "cpt_tonemap", "cpt_render_image", "cpt_render_progressive", "cpt_synchronize", "cpt_get_stats",
+    "cpt_upload_scene", "cpt_build_scene", "cpt_refit_scene", "cpt_download_tree", "cpt_render", "cpt_render_noalloc", "cpt_tonemap", "cpt_render_image", "cpt_render_image_multi", "cpt_render_progressive", "cpt_synchronize", "cpt_get_stats",
     "cpt_reset_stats", "cpt_extend_rays", "cpt_extend_rays_observed", "cpt_trace_rays", "cpt_camera_rays", "cpt_path_radiance", "cpt_probe_math", "cpt_probe_rng",
 ]
 # every symbol include/cpt_host.h declares
@@ -115,6 +115,11 @@ def amd():
         L.cpt_render_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp]
         L.cpt_tonemap.argtypes = [vp, vp, i32, i32, i32, vp]
         L.cpt_render_image.argtypes = [vp, C.POINTER(RenderParams), vp]
+        try:
+            L.cpt_render_image_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(RenderParams), vp, C.POINTER(i32)]
+        except AttributeError:  # only an older A/B build named by CPT_AMD_LIBRARY may lack an entry point
+            if not os.environ.get("CPT_AMD_LIBRARY"):
+                raise
         L.cpt_render_progressive.argtypes = [vp, C.POINTER(RenderParams), i32, vp, i32, vp, PROGRESS_FN, vp, C.POINTER(i32)]
         L.cpt_synchronize.argtypes = [vp]
         L.cpt_get_stats.argtypes = [vp, C.POINTER(Stats)]

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <cmath>
 #include <vector>
 
@@ -1179,6 +1180,74 @@ int cpt_render_progressive(cpt_ctx* c, const cpt_render_params* p, int32_t chunk
     (void)hipStreamSynchronize(c->stream);
     if (samples_done) *samples_done = done;
     return rc;
+}
+
+// One render on several GPUs of this process.  Context k renders a contiguous share of the sample indices of every pixel
+// (the first total % n contexts one more) from a host thread of its own into a buffer on its own GPU; the sums are then
+// brought to the first context's GPU one after the other, device to device, and added there in list order, so the result
+// is ((sum 0 + sum 1) + sum 2) + ... whatever the GPUs' timing.
+int cpt_render_image_multi(cpt_ctx* const* ctxs, int32_t n_ctx, const cpt_render_params* p, uint8_t* h_rgb, int32_t* samples_done) {
+    if (samples_done) *samples_done = 0;
+    if (!ctxs || n_ctx < 1 || !ctxs[0]) return CPT_EINVAL;
+    cpt_ctx* c0 = ctxs[0];
+    if (!p || !h_rgb) return fail(c0, CPT_EINVAL, "cpt_render_image_multi: NULL argument");
+    if (p->sample_end <= p->sample_begin) return fail(c0, CPT_EINVAL, "cpt_render_image_multi: empty sample range");
+    for (int k = 0; k < n_ctx; ++k) {
+        if (!ctxs[k]) return fail(c0, CPT_EINVAL, "cpt_render_image_multi: context %d is NULL", k);
+        for (int j = 0; j < k; ++j)
+            if (ctxs[j] == ctxs[k]) return fail(c0, CPT_EINVAL, "cpt_render_image_multi: context %d is listed twice", k);
+        if (!ctxs[k]->has_scene) return fail(c0, CPT_ENOSCENE, "cpt_render_image_multi: context %d has no scene", k);
+        DParams P;
+        int prc = make_params(ctxs[k], p, P);
+        if (prc != CPT_OK) { if (k) c0->err = ctxs[k]->err; return prc; }
+    }
+    const size_t n = (size_t)p->width * p->height * 3;
+    const int total = p->sample_end - p->sample_begin, base = total / n_ctx, extra = total % n_ctx;
+    std::vector<DevBuf> sums((size_t)n_ctx);
+    std::vector<int> rcs((size_t)n_ctx, CPT_OK), share((size_t)n_ctx, 0);
+    auto work = [&](int k) {
+        cpt_ctx* c = ctxs[k];
+        cpt_render_params q = *p;
+        q.sample_begin = p->sample_begin + k * base + std::min(k, extra);
+        q.sample_end = q.sample_begin + base + (k < extra ? 1 : 0);
+        share[(size_t)k] = q.sample_end - q.sample_begin;
+        if (share[(size_t)k] == 0 && k > 0) return;
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess) e = sums[(size_t)k].alloc(n * sizeof(double));
+        if (e == hipSuccess) e = hipMemsetAsync(sums[(size_t)k].p, 0, n * sizeof(double), c->stream);
+        if (e != hipSuccess) { rcs[(size_t)k] = fail(c, CPT_EHIP, "radiance sums: %s", hipGetErrorString(e)); return; }
+        int rc = share[(size_t)k] > 0 ? cpt_render(c, &q, (double*)sums[(size_t)k].p) : CPT_OK;
+        if (rc == CPT_OK) rc = cpt_synchronize(c);
+        rcs[(size_t)k] = rc;
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int k = 1; k < n_ctx; ++k) pool.emplace_back(work, k);
+        work(0);
+        for (std::thread& t : pool) t.join();
+    }
+    for (int k = 0; k < n_ctx; ++k)
+        if (rcs[(size_t)k] != CPT_OK) {
+            if (k) c0->err = "context " + std::to_string(k) + " (GPU " + std::to_string(ctxs[k]->device) + "): " + ctxs[k]->err;
+            return rcs[(size_t)k];
+        }
+    HIP_TRY(c0, hipSetDevice(c0->device));
+    DevBuf incoming, rgb;
+    if (n_ctx > 1) HIP_TRY(c0, incoming.alloc(n * sizeof(double)));
+    HIP_TRY(c0, rgb.alloc(n));
+    for (int k = 1; k < n_ctx; ++k) {
+        if (share[(size_t)k] == 0) continue;
+        // every context was synchronised above, so the source is complete; the copy and the add queue up on the first context's stream
+        HIP_TRY(c0, hipMemcpyPeerAsync(incoming.p, c0->device, sums[(size_t)k].p, ctxs[k]->device, n * sizeof(double), c0->stream));
+        launch_add_values(c0->stream, (double*)sums[0].p, (const double*)incoming.p, (long long)n, c0->max_blocks);
+        HIP_TRY(c0, hipGetLastError());
+    }
+    int rc = cpt_tonemap(c0, (const double*)sums[0].p, p->width, p->height, total, (uint8_t*)rgb.p);
+    if (rc != CPT_OK) return rc;
+    HIP_TRY(c0, hipMemcpyAsync(h_rgb, rgb.p, n, hipMemcpyDeviceToHost, c0->stream));
+    HIP_TRY(c0, hipStreamSynchronize(c0->stream));
+    if (samples_done) *samples_done = total;
+    return CPT_OK;
 }
 
 int cpt_synchronize(cpt_ctx* c) {

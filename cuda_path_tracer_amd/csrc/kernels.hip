@@ -925,6 +925,12 @@ __global__ void __launch_bounds__(CPT_BLOCK) k_megakernel(DScene sc, DParams P, 
 
 // ---- tonemap -----------------------------------------------------------------------------------
 // reference: src/path_tracer.cu:436-443
+// dst[i] += src[i]: radiance sums of another GPU, already copied to this one, joining this GPU's (the reduce of a render
+// split over several GPUs of one process)
+__global__ void __launch_bounds__(CPT_BLOCK) k_add_values(double* __restrict__ dst, const double* __restrict__ src, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = dst[i] + src[i];
+}
+
 __global__ void __launch_bounds__(CPT_BLOCK) k_tonemap(const double* __restrict__ accum, long long n_values, int spp,
                                                        uint8_t* __restrict__ rgb) {
     for (long long k = blockIdx.x * blockDim.x + threadIdx.x; k < n_values; k += (long long)gridDim.x * blockDim.x) {
@@ -1103,6 +1109,9 @@ void launch_megakernel(const LaunchCfg& L, const DScene& sc, const DParams& P, d
     int g = grid_for(P.n_pix_slots, 1 << 30);
     if (work) hipLaunchKernelGGL(k_megakernel<true>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, accum, work);
     else hipLaunchKernelGGL(k_megakernel<false>, dim3(g), dim3(CPT_BLOCK), 0, L.stream, sc, P, accum, work);
+}
+void launch_add_values(hipStream_t st, double* dst, const double* src, long long n_values, int max_blocks) {
+    hipLaunchKernelGGL(k_add_values, dim3(grid_for(n_values, max_blocks)), dim3(CPT_BLOCK), 0, st, dst, src, n_values);
 }
 void launch_tonemap(const LaunchCfg& L, const double* accum, long long n_values, int spp, uint8_t* rgb) {
     int g = grid_for(n_values, L.max_blocks);

@@ -189,6 +189,7 @@ void launch_shade(const LaunchCfg& L, const DScene& sc, const DParams& P, const 
                   uint32_t* counter_out, uint32_t cap, long long max_entries, unsigned long long* work);
 void launch_resolve(const LaunchCfg& L, const DParams& P, const Radiance& col, int batch_n, double* accum);
 void launch_megakernel(const LaunchCfg& L, const DScene& sc, const DParams& P, double* accum, unsigned long long* work);
+void launch_add_values(hipStream_t st, double* dst, const double* src, long long n_values, int max_blocks);
 void launch_tonemap(const LaunchCfg& L, const double* accum, long long n_values, int spp, uint8_t* rgb);
 void launch_trace_rays(const LaunchCfg& L, const DScene& sc, int n, const double* o3, const double* d3, int* tri, double* t,
                        double* normal, unsigned long long* vhash, int* counts, uint8_t* bitmap, int bitmap_stride);

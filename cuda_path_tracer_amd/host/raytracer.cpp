@@ -190,52 +190,37 @@ void RayTracer::renderGPU(int w, int h, int mode) {
     }
 }
 
-// One render on several GPUs of this machine: GPU k of n renders a contiguous share of the sample indices of
-// every pixel (the first spp % n GPUs one more) from a host thread of its own, through a context of its own, and
-// hands back fp64 radiance sums; they are added in list order and tonemapped with k_tonemap's formula.  A
-// sample's paths depend only on (pixel, sample index, seed), so the sample set is the single-GPU one; only the
-// association of the final additions differs.  No reference counterpart (the reference drives one GPU).
-void RayTracer::renderMultiGPU(int w, int h, const cpt_render_params& p) {
+// One render on several GPUs of this machine: a context per listed GPU is created and given the scene from a host
+// thread of its own (uploads of large scenes run side by side), then cpt_render_image_multi deals the samples to
+// them, adds the radiance sums on the first GPU (device-to-device copies, one add kernel per peer, list order) and
+// tonemaps there.  A sample's paths depend only on (pixel, sample index, seed), so the sample set is the single-GPU
+// one; only the association of the final additions differs.  No reference counterpart (the reference drives one GPU).
+void RayTracer::renderMultiGPU(int /*w*/, int /*h*/, const cpt_render_params& p) {
     const size_t n = options.devices.size();
     more_ctx_.resize(n - 1, nullptr);
     const cpt_scene_desc d = sceneDesc();
     const bool on_device = scene_->nodes.empty() && scene_->tris.size() > 1;
-    std::vector<std::vector<double>> sums(n, std::vector<double>((size_t)w * h * 3, 0.0));
     std::vector<std::string> errors(n);
-    std::vector<int> done(n, 0);
-    auto work = [&](size_t k) {
+    auto prepare = [&](size_t k) {
         cpt_ctx*& c = k == 0 ? ctx_ : more_ctx_[k - 1];
         if (!c && cpt_create(options.devices[k], &c) != CPT_OK) { errors[k] = cpt_last_error(nullptr); c = nullptr; return; }
-        if (k > 0 && options.batch_paths > 0 && cpt_set_option(c, "batch_paths", options.batch_paths) != CPT_OK) { errors[k] = cpt_last_error(c); return; }
-        if (k > 0 && !applyWalkOptions(c)) { errors[k] = cpt_last_error(c); return; }
-        if (k > 0 && (on_device ? cpt_build_scene(c, &d) : cpt_upload_scene(c, &d)) != CPT_OK) { errors[k] = cpt_last_error(c); return; }
-        const int total = p.sample_end - p.sample_begin, base = total / (int)n, extra = total % (int)n;
-        cpt_render_params q = p;
-        q.sample_begin = p.sample_begin + (int)k * base + std::min((int)k, extra);
-        q.sample_end = q.sample_begin + base + ((int)k < extra ? 1 : 0);
-        if (q.sample_end == q.sample_begin) return;
-        std::vector<unsigned char> rgb((size_t)w * h * 3);
-        int32_t got = 0;
-        if (cpt_render_progressive(c, &q, q.sample_end - q.sample_begin, sums[k].data(), 0, rgb.data(), nullptr, nullptr, &got) != CPT_OK) {
-            errors[k] = cpt_last_error(c);
-            return;
-        }
-        done[k] = got;
+        if (k == 0) return;  // the first context was set up by the caller
+        if (options.batch_paths > 0 && cpt_set_option(c, "batch_paths", options.batch_paths) != CPT_OK) { errors[k] = cpt_last_error(c); return; }
+        if (!applyWalkOptions(c)) { errors[k] = cpt_last_error(c); return; }
+        if ((on_device ? cpt_build_scene(c, &d) : cpt_upload_scene(c, &d)) != CPT_OK) { errors[k] = cpt_last_error(c); return; }
     };
     std::vector<std::thread> pool;
-    for (size_t k = 1; k < n; ++k) pool.emplace_back(work, k);
-    work(0);
+    for (size_t k = 1; k < n; ++k) pool.emplace_back(prepare, k);
+    prepare(0);
     for (std::thread& t : pool) t.join();
     for (size_t k = 0; k < n; ++k)
         if (!errors[k].empty()) { error_ = "GPU " + std::to_string(options.devices[k]) + ": " + errors[k]; return; }
-    int have = 0;
-    for (size_t k = 0; k < n; ++k) have += done[k];
-    for (size_t i = 0; i < sums[0].size(); ++i) {
-        double sum = sums[0][i];
-        for (size_t k = 1; k < n; ++k) sum += sums[k][i];
-        double c = sum / have;
-        c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
-        buffer_[i] = (unsigned char)(int)(255.0 * c);
+    std::vector<cpt_ctx*> all(1, ctx_);
+    all.insert(all.end(), more_ctx_.begin(), more_ctx_.end());
+    int32_t have = 0;
+    if (cpt_render_image_multi(all.data(), (int32_t)all.size(), &p, buffer_.data(), &have) != CPT_OK) {
+        error_ = cpt_last_error(ctx_);
+        return;
     }
     samples_in_image_ = have;
 }

@@ -128,6 +128,16 @@ class Renderer:
     def synchronize(self):
         self._check(self._L.cpt_synchronize(self._h), "cpt_synchronize")
 
+    def render_image_multi(self, others, params):
+        """cpt_render_image_multi: this renderer and `others` (each with the same scene in place, normally one per GPU)
+        share the samples of one render; the radiance sums are added on this renderer's GPU.  Returns (rgb, samples)."""
+        rgb = np.zeros((params.height, params.width, 3), np.uint8)
+        handles = (C.c_void_p * (1 + len(others)))(self._h, *[o._h for o in others])
+        done = C.c_int32(0)
+        self._check(self._L.cpt_render_image_multi(handles, len(handles), C.byref(params), _vp(rgb), C.byref(done)),
+                    "cpt_render_image_multi")
+        return rgb, done.value
+
     def render_progressive(self, params, chunk_spp, accum=None, accum_samples=0, on_progress=None):
         """cpt_render_progressive: returns (rgb (h, w, 3) uint8, samples this call added).  `accum`, a
         float64 array (h, w, 3), carries the radiance sums between calls (resume / checkpoint);

@@ -270,6 +270,19 @@ int cpt_render_progressive(cpt_ctx* ctx, const cpt_render_params* params, int32_
                            int32_t accum_samples, uint8_t* h_rgb, cpt_progress_fn progress, void* user,
                            int32_t* samples_done);
 
+/* One whole-image render on several GPUs of this process (cpt_render_image split by samples).  contexts[0..n) are distinct
+ * contexts, normally one per GPU, each with the same scene in place.  Context k renders a contiguous share of the sample
+ * indices [sample_begin, sample_end) of every pixel -- the first (count % n) contexts one sample more -- from a host thread
+ * of its own into radiance sums on its own GPU.  The sums are then copied device to device to contexts[0]'s GPU
+ * (hipMemcpyPeerAsync: over xGMI between the GPUs of a node) and added there by a kernel, one peer after the other in list
+ * order, and the total is tonemapped there into h_rgb (host, width*height*3 bytes, bottom row first).  A sample's paths
+ * depend only on (pixel, sample index, seed), so the sample set is the single-GPU one; the sums are those of a
+ * single-GPU render except for the association of the n - 1 final additions per value.  *samples_done (nullable)
+ * receives the samples in the image.  Blocking; errors of any context are reported through contexts[0].
+ * No counterpart in the reference, which drives one GPU (src/path_tracer.cu:507-551). */
+int cpt_render_image_multi(cpt_ctx* const* contexts, int32_t n_contexts, const cpt_render_params* params, uint8_t* h_rgb,
+                           int32_t* samples_done);
+
 /* Wait for everything queued on the context's stream. */
 int cpt_synchronize(cpt_ctx* ctx);
 int cpt_get_stats(cpt_ctx* ctx, cpt_stats* out);

@@ -720,6 +720,45 @@ def test_cli_splits_samples_over_several_contexts(tmp_path):
     assert r.returncode != 0
 
 
+def test_render_split_over_contexts_adds_the_sums_on_the_first_gpu(gpu_scene, host_scenes):
+    """cpt_render_image_multi, rehearsed with three contexts on the one GPU (7 samples -> 3 + 2 + 2): the image is the
+    tonemap of ((sum 0 + sum 1) + sum 2), each sum rendered by its context alone -- checked against those sums made one
+    by one and added on the host in the same order.  Bad lists are refused."""
+    import torch
+    import cuda_path_tracer_amd as cpt
+    name = "cornell-box2-transmissive"
+    g = gpu_scene(name)
+    others = [cpt.Renderer(0), cpt.Renderer(0)]
+    try:
+        for o in others:
+            o.upload(host_scenes(name))
+        w, h, depth = 61, 45, 5
+        rgb, done = g.render_image_multi(others, g.params(w, h, 2, 9, depth))
+        assert done == 7
+        total = np.zeros((h, w, 3))
+        for k, (a, b) in enumerate([(2, 5), (5, 7), (7, 9)]):
+            acc = torch.zeros(h, w, 3, dtype=torch.float64, device="cuda")
+            g.render_into(acc.data_ptr(), g.params(w, h, a, b, depth))
+            g.synchronize()
+            total = acc.cpu().numpy() if k == 0 else total + acc.cpu().numpy()
+        want = (255.0 * np.clip(total / 7, 0.0, 1.0)).astype(np.uint8)
+        assert np.array_equal(rgb, want)
+        # more contexts than samples: the last ones render nothing
+        rgb2, done2 = g.render_image_multi(others, g.params(w, h, 0, 2, depth))
+        assert done2 == 2 and np.array_equal(rgb2, g.render_image(g.params(w, h, 0, 2, depth)))
+        with pytest.raises(cpt.CptError):
+            g.render_image_multi([others[0], others[0]], g.params(w, h, 0, 4, depth))
+        bare = cpt.Renderer(0)
+        try:
+            with pytest.raises(cpt.CptError):
+                g.render_image_multi([bare], g.params(w, h, 0, 4, depth))
+        finally:
+            bare.close()
+    finally:
+        for o in others:
+            o.close()
+
+
 def test_progressive_and_resumed_renders_are_bit_identical(gpu_scene):
     """cpt_render_progressive: chunked, stopped-and-resumed and single-call renders hold the same
     radiance sums bit for bit and the same image; the progress callback sees every chunk."""
