@@ -303,9 +303,13 @@ static int scene_mode(const cpt_ctx* c) {
     if (!c->has_scene) return 0;
     const int stack = variant_cull(c) ? c->measured_height - 2 : std::min(c->stack_need, c->measured_height - 2);
     if (stack > CPT_PW_STACK_LDS_HOST) return 0;
-    // 128-byte slots the scene takes in the record cache (binary32 node records are half a slot each)
-    const long long slots = variant_f32(c) ? (c->sc.n_nodes + 1) / 2 + (long long)c->sc.n_tris : (long long)c->sc.n_nodes + c->sc.n_tris;
-    return slots <= (variant_f32(c) ? CPT_PW_CACHE_RECORDS_HOST : CPT_PW_PLANAR_SLOTS_HOST) ? 2 : 1;
+    if (variant_f32(c)) {  // 128-byte slots the scene takes in the record cache (binary32 node records are half a slot each)
+        const long long slots = (c->sc.n_nodes + 1) / 2 + (long long)c->sc.n_tris;
+        return slots <= CPT_PW_CACHE_RECORDS_HOST ? 2 : 1;
+    }
+    // the exact variants' resident instance has a record layout, a stack and a cache size of its own
+    const bool cull = variant_cull(c);
+    return stack <= cpt_pw_resident_stack(cull) && cpt_pw_resident_bytes(c->sc.n_nodes, c->sc.n_tris) <= cpt_pw_resident_cache_bytes(cull) ? 2 : 1;
 }
 
 // Rays a wave claims at a time.  A claim stalls the wave for an atomic's round trip; a chunk is also what a wave may be
@@ -351,7 +355,7 @@ static const cpt_scene_desc* order_scene(cpt_ctx* c, const cpt_scene_desc* s, bo
     const int n = s->n_tris;
     if (new_order) {  // into `os`: the context keeps the old scene's tables until the old scene is gone (commit_order)
         const long long n_nodes = with_nodes ? s->n_nodes : (long long)n - 1;
-        if (n_nodes + n > CPT_PW_PLANAR_SLOTS_HOST) {
+        if (cpt_pw_resident_bytes(n_nodes, n) > cpt_pw_resident_cache_bytes(false)) {  // it cannot live in LDS whole
             std::vector<double> area((size_t)n);
             for (int i = 0; i < n; ++i) area[(size_t)i] = box_area_of(s->tris[i]);
             os.tri_ext.resize((size_t)n);

@@ -67,23 +67,28 @@ __device__ __forceinline__ bool slab_hit(double lx, double ly, double lz, double
 }
 
 // The same verdict as slab_hit, usually without dividing.  With r = 1/d rounded once per ray,
-// a = (plane - o) * r differs from the reference's rounded quotient t = (plane - o) / d by at most
-// 3.1 ulp of a (the subtraction is the reference's own, so there is no absolute error term and
-// rays that start on a box plane are decided like any other).
+// a = (plane - o) * r differs from the reference's rounded quotient t = (plane - o) / d by a relative 4.1 * 2^-53 at
+// most (three roundings, one more for a reciprocal that is within one ulp; the subtraction is the reference's own, so
+// there is no absolute error term and rays that start on a box plane are decided like any other).
 //
 // The reference's verdict is "every axis' near t <= every axis' far t, and the smallest far t is
 // >= 1e-12" (its early returns can never be undone by a later axis).  On one axis near <= far always
 // holds because rounding is monotonic, and a box that is flat on an axis has near == far there, so
 // only the six cross-axis orderings may be judged by their distance from equality:
 //   G = min over axes k of (far_k - largest near of the other two axes).
-// With TN the largest near and TF the smallest far product and M = 2e-15 (|TF| + |TN|) + 1e-300:
+// With TF the smallest far product and M = 4e-15 |TF| + 1e-300:
 //   hit   is certain when  G >  M  and TF > 1e-12 (1 + 1e-15)
 //   miss  is certain when  G < -M  or  TF < 1e-12 (1 - 1e-15)
-// One margin serves all six orderings: every near is <= TN and every far is >= TF; once TF > 0
-// (else the epsilon test alone says miss) an ordering far_k - near_i with near_i <= 0 holds with
-// room |far_k| + |near_i|, and one with 0 < near_i <= TN that clears 2e-15 TN = 18 ulp of near_i
-// clears its own 3.1 ulp (|far_k| + |near_i|) bound; symmetrically for a violated ordering.  The
-// floor covers the subnormal range.  Anything else is "not sure" and the caller redoes the box with
+// One margin serves all six orderings, and it needs TF only.  The epsilon test alone says miss unless TF > 0, so let
+// TF > 0 (then every far is positive, in exact arithmetic as well: a product has its quotient's sign).
+// G > M: on TF's axis j the far is above every other axis' near by G and above its own near by monotonicity, so no near
+// exceeds TF.  An ordering far_k >= near_i with near_i <= 0 holds in exact arithmetic by the signs alone; one with
+// 0 < near_i <= TF <= far_k has far_k - near_i >= G > 4e-15 near_i, and a difference x > 4e-15 near_i clears the
+// 4.6e-16 (2 near_i + x) that the two products can be off by together (the roundings of the difference and of M are
+// relative 2^-53 of numbers that have four times that room).
+// G < -M: the largest near TN lies on another axis than TF (on TF's own axis every near is <= TF and G would be >= 0),
+// so G = TF - TN and TN - TF > 4e-15 TF clears the same bound: that ordering is violated in exact arithmetic too.
+// The floor covers the subnormal range.  Anything else is "not sure" and the caller redoes the box with
 // slab_hit.  Infinite intermediates end up as "not sure"; the caller must not use this test at all
 // for a ray with a zero direction component (the reference skips such an axis, which the products
 // cannot express).
@@ -103,9 +108,9 @@ struct SlabRay {
 };
 __device__ __forceinline__ SlabRay slab_prepare(const dvec3& o, const dvec3& d) {
     SlabRay s;
-    // The reciprocal need not be the correctly rounded one: the margin below is 2e-15 (|TF| + |TN|), some nine ulp of
-    // the compared values each way, against the 3.1 ulp of a correctly rounded reciprocal's products; one more ulp in r
-    // makes that 4.1.  The hardware estimate refined twice by Newton's step (error below one ulp) costs five
+    // The reciprocal need not be the correctly rounded one: the margin of the test (slab_verdict) has four times the
+    // room that the products of a reciprocal within one ulp need, and a correctly rounded one would only take a quarter
+    // off that need.  The hardware estimate refined twice by Newton's step (error below one ulp) costs five
     // instructions where the IEEE division takes thirteen, three times per ray.  Zero, infinite and NaN components
     // come out infinite or NaN and send the ray down the exact path, as before.
     s.r = dv(fast_reciprocal(d.x), fast_reciprocal(d.y), fast_reciprocal(d.z));
@@ -115,27 +120,40 @@ __device__ __forceinline__ SlabRay slab_prepare(const dvec3& o, const dvec3& d) 
                      fabs(o.x) < 1e300 && fabs(o.y) < 1e300 && fabs(o.z) < 1e300);
     return s;
 }
+// The part of the test that follows the products: n* / f* are each axis' near and far product.
+__device__ __forceinline__ bool slab_verdict(double nx, double ny, double nz, double fx, double fy, double fz, bool& sure,
+                                             double& t_enter) {
+    double cx = fmax(ny, nz), cy = fmax(nx, nz), cz = fmax(nx, ny);
+    double tf = fmin(fx, fmin(fy, fz));
+    double g = fmin(fx - cx, fmin(fy - cy, fz - cz));
+    double m = fma(fabs(tf), 4e-15, 1e-300);
+    bool hit = (g > m) && (tf > 1.000000000000001e-12);
+    sure = hit || (g < -m) || (tf < 0.999999999999999e-12);
+    t_enter = fmax(cz, nz);  // only the culling walks look at it
+    return hit;
+}
 __device__ __forceinline__ bool slab_filtered(double lx, double ly, double lz, double hx, double hy, double hz,
                                               const dvec3& o, const SlabRay& s, bool& sure, double& t_enter) {
     double x1 = (lx - o.x) * s.r.x, x2 = (hx - o.x) * s.r.x;
     double y1 = (ly - o.y) * s.r.y, y2 = (hy - o.y) * s.r.y;
     double z1 = (lz - o.z) * s.r.z, z2 = (hz - o.z) * s.r.z;
-    double nx = fmin(x1, x2), fx = fmax(x1, x2);
-    double ny = fmin(y1, y2), fy = fmax(y1, y2);
-    double nz = fmin(z1, z2), fz = fmax(z1, z2);
-    double cx = fmax(ny, nz), cy = fmax(nx, nz), cz = fmax(nx, ny);
-    double tn = fmax(cz, nz), tf = fmin(fx, fmin(fy, fz));
-    double g = fmin(fx - cx, fmin(fy - cy, fz - cz));
-    double m = fma(fabs(tf) + fabs(tn), 2e-15, 1e-300);
-    bool hit = (g > m) && (tf > 1.000000000000001e-12);
-    sure = hit || (g < -m) || (tf < 0.999999999999999e-12);
-    t_enter = tn;
-    return hit;
+    return slab_verdict(fmin(x1, x2), fmin(y1, y2), fmin(z1, z2), fmax(x1, x2), fmax(y1, y2), fmax(z1, z2), sure, t_enter);
 }
 __device__ __forceinline__ bool slab_filtered(double lx, double ly, double lz, double hx, double hy, double hz,
                                               const dvec3& o, const SlabRay& s, bool& sure) {
     double unused;
     return slab_filtered(lx, ly, lz, hx, hy, hz, o, s, sure, unused);
+}
+// The same test for a caller that already knows, per axis, which of the box's two planes the ray meets first: `near`
+// holds the lower plane of every axis on which the ray moves up (r > 0) and the upper plane of the others, `far` the
+// opposite ones.  Rounding is monotonic, so on an axis with r > 0 the lower plane's product is the smaller one (or they
+// are equal), with r < 0 the upper plane's: the minima and maxima of slab_filtered select exactly these values and need
+// not be taken.  (Which plane goes where is immaterial to slab_hit, whose swap is symmetric, and to a ray with a
+// non-finite reciprocal, which is sent there.)
+__device__ __forceinline__ bool slab_selected(double near_x, double near_y, double near_z, double far_x, double far_y, double far_z,
+                                              const dvec3& o, const SlabRay& s, bool& sure, double& t_enter) {
+    return slab_verdict((near_x - o.x) * s.r.x, (near_y - o.y) * s.r.y, (near_z - o.z) * s.r.z,
+                        (far_x - o.x) * s.r.x, (far_y - o.y) * s.r.y, (far_z - o.z) * s.r.z, sure, t_enter);
 }
 
 // Ray/triangle test (reference: src/gpu/GPUTrimesh.cuh:59-113): plane hit, back-face cull unless

@@ -249,6 +249,8 @@ typedef __attribute__((address_space(3))) unsigned char lds_byte;
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) v2d lds_v2d;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) int32_t lds_i32;
+typedef __attribute__((address_space(3))) double lds_f64;
 __device__ __forceinline__ double2 lds_piece(const lds_byte* p) {
     v2d v = *(const lds_v2d*)p;
     return make_double2(v.x, v.y);
@@ -473,12 +475,17 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                                                               ExtendObserve obs, dvec3 eye) {
     static_assert(!(F32 && EYE), "the shared-origin records exist for the exact variants only");
     constexpr bool RESIDENT = MODE == 2, LDS_STACK = MODE >= 1;
+    // SEL: the resident instance of the exact variants keeps its records in the layout described at
+    // CPT_PW_RESIDENT_NODE_BYTES: every lane reads, per child and axis, the plane its ray meets first and the one it
+    // meets last (slab_selected), and the instance without culling trades half of its node stack for record space.
+    constexpr bool SEL = RESIDENT && !F32;
     const void* const node_recs = EYE ? (const void*)sc.nodes_eye : (const void*)sc.nodes_pw;
     const void* const tri_recs = EYE ? (const void*)sc.tris_eye : (const void*)sc.tris;
     typedef PwPlan<F32> Plan;
-    constexpr int kStackLds = Plan::STACK_LDS, kLeafCap = Plan::LEAF_CAP;
+    constexpr int kStackLds = (SEL && !CULL) ? CPT_PW_RESIDENT_STACK : Plan::STACK_LDS, kLeafCap = Plan::LEAF_CAP;
     constexpr int kPlaneBytes = F32 ? 0 : Plan::PLANE_BYTES;  // 0: whole records with rotated pieces (fetch_record)
-    __shared__ __attribute__((aligned(128))) unsigned char s_cache[Plan::CACHE_BYTES];
+    constexpr int kCacheBytes = Plan::CACHE_BYTES + (Plan::STACK_LDS - kStackLds) * 4 * CPT_PW_THREADS;
+    __shared__ __attribute__((aligned(128))) unsigned char s_cache[kCacheBytes];
     __shared__ uint32_t s_nodes[CPT_PW_WAVES][kStackLds][CPT_WAVE];
     __shared__ uint32_t s_leaves[CPT_PW_WAVES][kLeafCap][CPT_WAVE];
     const uint32_t lane = threadIdx.x & (CPT_WAVE - 1), wave = threadIdx.x / CPT_WAVE;
@@ -516,6 +523,25 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
             int r = tri_first + (i >> 3), c = i & 7;
             *(double2*)(s_cache + (size_t)r * 128 + (((uint32_t)c ^ (((uint32_t)r >> 1) & 7u)) << 4)) =
                 *(const double2*)((const unsigned char*)sc.tris + (size_t)(i >> 3) * 128 + c * 16);
+        }
+    } else if (SEL) {  // the host has checked that all of it fits (scene_mode)
+        for (int i = (int)threadIdx.x; i < sc.n_nodes * 21; i += CPT_PW_THREADS) {
+            const int r = i / 21, e = i - r * 21;
+            const double* src = (const double*)((const unsigned char*)node_recs + (size_t)r * 128);  // lower x y z, upper x y z of the left child, of the right child, references, ids
+            double v = 0.0;
+            if (e < 18) {
+                const int child = e / 9, axis = (e - child * 9) / 3, j = e - child * 9 - axis * 3;  // (upper, lower, upper)
+                v = src[child * 6 + (j == 1 ? axis : 3 + axis)];
+            } else if (e < 20) {
+                v = src[12 + (e - 18)];
+            }
+            *(double*)(s_cache + (size_t)r * CPT_PW_RESIDENT_NODE_BYTES + (size_t)e * 8) = v;
+        }
+        const int tri_lds = (sc.n_nodes * CPT_PW_RESIDENT_NODE_BYTES + 15) / 16 * 16;
+        for (int i = (int)threadIdx.x; i < sc.n_tris * 7; i += CPT_PW_THREADS) {
+            const int r = i / 7, c = i - r * 7;
+            *(double2*)(s_cache + tri_lds + (size_t)r * CPT_PW_RESIDENT_TRI_BYTES + (size_t)c * 16) =
+                *(const double2*)((const unsigned char*)tri_recs + (size_t)r * 128 + c * 16);
         }
     } else {
         for (int i = (int)threadIdx.x; i < (cached_nodes + cached_tris) * 8; i += CPT_PW_THREADS) {
@@ -558,6 +584,11 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     uint32_t pos = 0;  // stream position of this lane's ray
     dvec3 o = EYE ? eye : dv(0, 0, 0), d = dv(0, 0, 1);
     SlabRay sr = slab_prepare(o, dv(1, 1, 1));
+    // SEL: byte offsets into a node's record of the left child's (near, far) plane pair of each axis for this lane's ray:
+    // the axis' triple starts at 24 * axis and holds (upper, lower, upper), so a ray that moves up the axis reads from
+    // its second double on, one that moves down from its first
+    uint32_t sel_x = 8, sel_y = 32, sel_z = 56;
+    const uint32_t tri_lds = (uint32_t)((sc.n_nodes * CPT_PW_RESIDENT_NODE_BYTES + 15) / 16 * 16);
     Ray32 q32 = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double best_t = -1.0;
     int best_tri = -1;
@@ -598,6 +629,11 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                     load_ray_geometry(in, pos, o, d);
                 }
                 sr = slab_prepare(o, d);
+                if (SEL) {
+                    sel_x = sr.r.x < 0 ? 0u : 8u;
+                    sel_y = sr.r.y < 0 ? 24u : 32u;
+                    sel_z = sr.r.z < 0 ? 48u : 56u;
+                }
                 if (F32) q32 = ray32_prepare(o, sr, scene_extent);
                 best_t = -1.0;
                 best_tri = -1;
@@ -651,6 +687,27 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                     slab32_pair(lox, loy, loz, hix, hiy, hiz, q32, hl, hr, el, er);
                     enter_l = (double)el;
                     enter_r = (double)er;
+                } else if (SEL) {
+                    const uint32_t rec = __umul24((uint32_t)node, CPT_PW_RESIDENT_NODE_BYTES);
+                    // (volatile keeps the twelve reads apart: paired up as ds_read2_b64 they would take the LDS array twice as long)
+                    const volatile lds_f64* px = (const volatile lds_f64*)(cache + rec + sel_x);  // [0], [1]: the left child's near and far plane; [9], [10]: the right child's
+                    const volatile lds_f64* py = (const volatile lds_f64*)(cache + rec + sel_y);
+                    const volatile lds_f64* pz = (const volatile lds_f64*)(cache + rec + sel_z);
+                    const double lnx = px[0], lfx = px[1], rnx = px[9], rfx = px[10];
+                    const double lny = py[0], lfy = py[1], rny = py[9], rfy = py[10];
+                    const double lnz = pz[0], lfz = pz[1], rnz = pz[9], rfz = pz[10];
+                    const lds_i32* pr = (const lds_i32*)(cache + rec + 144);
+                    refs = make_int2(pr[0], pr[1]);
+                    if (COUNT) ids = make_int2(pr[2], pr[3]);
+                    bool sure_l, sure_r;
+                    const dvec3 box_o = EYE ? dv(0, 0, 0) : o;
+                    hl = slab_selected(lnx, lny, lnz, lfx, lfy, lfz, box_o, sr, sure_l, enter_l);
+                    hr = slab_selected(rnx, rny, rnz, rfx, rfy, rfz, box_o, sr, sure_r, enter_r);
+                    if (sr.exact_only || !(sure_l && sure_r)) {
+                        if (COUNT) exact++;
+                        hl = slab_hit(lnx, lny, lnz, lfx, lfy, lfz, box_o, d, enter_l);
+                        hr = slab_hit(rnx, rny, rnz, rfx, rfy, rfz, box_o, d, enter_r);
+                    }
                 } else {
                     const Rec7 r = fetch_record<RESIDENT, kPlaneBytes>(node_recs, cache, 0, cached_nodes, node);
                     refs = make_int2(__double2loint(r.p6.x), __double2hiint(r.p6.x));
@@ -732,7 +789,14 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 if (leaf_top != leaf_base) {
                     leaf_top -= CPT_WAVE;
                     int tri = (int)~*leaf_top;
-                    Rec7 q = fetch_record<RESIDENT, kPlaneBytes>(tri_recs, cache, tri_first, cached_tris, tri);
+                    Rec7 q;
+                    if (SEL) {
+                        const lds_byte* rec = cache + tri_lds + __umul24((uint32_t)tri, CPT_PW_RESIDENT_TRI_BYTES);
+                        q.p0 = lds_piece(rec); q.p1 = lds_piece(rec + 16); q.p2 = lds_piece(rec + 32); q.p3 = lds_piece(rec + 48);
+                        q.p4 = lds_piece(rec + 64); q.p5 = lds_piece(rec + 80); q.p6 = lds_piece(rec + 96);
+                    } else {
+                        q = fetch_record<RESIDENT, kPlaneBytes>(tri_recs, cache, tri_first, cached_tris, tri);
+                    }
                     const uint32_t flags = (uint32_t)__double2hiint(q.p6.x);
                     const uint32_t rank = (uint32_t)__double2loint(EYE ? q.p6.x : q.p6.y);  // see k_eye_records
                     bool gate = true;

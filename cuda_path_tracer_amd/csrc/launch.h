@@ -150,6 +150,25 @@ inline size_t cpt_stream_positions(size_t n) { return (size_t)cpt_segment_cap(n)
 #ifndef CPT_PW_THREADS_HOST
 #define CPT_PW_THREADS_HOST 1024
 #endif
+// The exact variants' instance for a scene that lives in LDS whole ("resident") keeps its records in a layout of its
+// own: a node as 21 doubles -- per child and axis the triple (upper, lower, upper) plane, so that a lane reads the plane
+// its ray meets first and the one it meets last as two consecutive doubles at an offset it fixes once per ray, then the
+// two child references and the two canonical ids, then one double of padding that makes the stride an odd number of
+// 8-byte bank pairs -- and a triangle as the seven 16-byte pieces of its record that are ever read (an odd number of
+// 16-byte bank groups).  Such a scene's tree is low: the instance without culling holds CPT_PW_RESIDENT_STACK node-stack
+// entries per lane -- enough for any tree over the 285 triangles that fit, whose walk in stack-minimal order postpones
+// at most log2(inner nodes) + 1 of them -- and gives the rest of the stack's LDS to the records.
+#define CPT_PW_RESIDENT_NODE_BYTES 168
+#define CPT_PW_RESIDENT_TRI_BYTES 112
+#define CPT_PW_RESIDENT_STACK 9
+inline int cpt_pw_resident_stack(bool cull) { return cull ? CPT_PW_STACK_LDS_HOST : CPT_PW_RESIDENT_STACK; }
+inline long long cpt_pw_resident_cache_bytes(bool cull) {
+    return (long long)CPT_PW_CACHE_RECORDS_HOST * 128 + (long long)(CPT_PW_STACK_LDS_HOST - cpt_pw_resident_stack(cull)) * 4 * CPT_PW_THREADS_HOST;
+}
+inline long long cpt_pw_resident_tri_base(long long n_nodes) { return (n_nodes * CPT_PW_RESIDENT_NODE_BYTES + 15) / 16 * 16; }
+inline long long cpt_pw_resident_bytes(long long n_nodes, long long n_tris) {
+    return cpt_pw_resident_tri_base(n_nodes) + n_tris * CPT_PW_RESIDENT_TRI_BYTES;
+}
 
 // What the counting instances of the extend kernels can report per ray besides the hit (all nullable; indexed by
 // stream position): the order-free hash of the canonical ids of every node whose box was tested, and one bitmap row

@@ -558,13 +558,14 @@ def test_binary32_inner_nodes_with_planes_beyond_the_binary32_range(gpu, oracle,
 
 
 def test_scene_sizes_around_the_record_cache_capacity(gpu):
-    """The persistent extend kernel keeps 585 records in LDS in the exact variants (512 slots in the binary32 ones, a
-    node record taking half a slot there) and runs another template instance when the whole scene fits.  Triangle
-    counts on both sides of every such boundary (a device-built tree over n triangles has n - 1 nodes: 2n - 1 <= 585
-    up to n = 293, 1.5n <= 512 up to n = 341) must give the hits of the one-ray-per-thread kernel, bit for bit."""
+    """The persistent extend kernel runs another template instance when the whole scene fits its LDS record cache: in the
+    exact variants 168 bytes per node and 112 per triangle in 79 872 bytes (67 584 with culling), which a device-built
+    tree over n triangles (n - 1 nodes) fits up to n = 285 (241); in the binary32 ones 512 slots of 128 bytes, a node
+    record taking half a slot, up to n = 341.  A scene beyond that keeps a prefix of each array there.  Triangle counts
+    on both sides of every such boundary must give the hits of the one-ray-per-thread kernel, bit for bit."""
     from cuda_path_tracer_amd import HostScene
     rng = np.random.default_rng(41)
-    for n in (255, 256, 257, 292, 293, 294, 340, 341, 342, 343, 600):
+    for n in (240, 241, 242, 255, 256, 257, 284, 285, 286, 287, 340, 341, 342, 343, 600):
         tris = [_small_tri(rng.uniform(-1, 1, 3), 10.0 ** rng.uniform(-2, -0.5), rng) for _ in range(n)]
         gpu.build(HostScene(text=_mesh_text(tris)))
         o = rng.uniform(-1.3, 1.3, (6000, 3))
