@@ -76,7 +76,7 @@ __device__ __forceinline__ bool slab_hit(double lx, double ly, double lz, double
 // holds because rounding is monotonic, and a box that is flat on an axis has near == far there, so
 // only the six cross-axis orderings may be judged by their distance from equality:
 //   G = min over axes k of (far_k - largest near of the other two axes).
-// With TF the smallest far product and M = 4e-15 |TF| + 1e-300:
+// With TF the smallest far product and M = 4e-15 |TF|:
 //   hit   is certain when  G >  M  and TF > 1e-12 (1 + 1e-15)
 //   miss  is certain when  G < -M  or  TF < 1e-12 (1 - 1e-15)
 // One margin serves all six orderings, and it needs TF only.  The epsilon test alone says miss unless TF > 0, so let
@@ -88,7 +88,8 @@ __device__ __forceinline__ bool slab_hit(double lx, double ly, double lz, double
 // relative 2^-53 of numbers that have four times that room).
 // G < -M: the largest near TN lies on another axis than TF (on TF's own axis every near is <= TF and G would be >= 0),
 // so G = TF - TN and TN - TF > 4e-15 TF clears the same bound: that ordering is violated in exact arithmetic too.
-// The floor covers the subnormal range.  Anything else is "not sure" and the caller redoes the box with
+// (M needs no floor: it only decides where TF >= 1e-12 (1 - 1e-15), and there it is at least 4e-27; products down in the
+// subnormal range, whose error is absolute, are nears that far below every far that counts.)  Anything else is "not sure" and the caller redoes the box with
 // slab_hit.  Infinite intermediates end up as "not sure"; the caller must not use this test at all
 // for a ray with a zero direction component (the reference skips such an axis, which the products
 // cannot express).
@@ -126,7 +127,7 @@ __device__ __forceinline__ bool slab_verdict(double nx, double ny, double nz, do
     double cx = fmax(ny, nz), cy = fmax(nx, nz), cz = fmax(nx, ny);
     double tf = fmin(fx, fmin(fy, fz));
     double g = fmin(fx - cx, fmin(fy - cy, fz - cz));
-    double m = fma(fabs(tf), 4e-15, 1e-300);
+    double m = fabs(tf) * 4e-15;
     bool hit = (g > m) && (tf > 1.000000000000001e-12);
     sure = hit || (g < -m) || (tf < 0.999999999999999e-12);
     t_enter = fmax(cz, nz);  // only the culling walks look at it

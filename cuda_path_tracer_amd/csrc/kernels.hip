@@ -743,10 +743,12 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
                 if (COUNT) steps++;
                 // parked without a branch: the entry is written whether or not the child is a leaf that was hit (there
                 // is room for two, and nothing beyond the top is ever read), only the top moves conditionally
-                *leaf_top = (uint32_t)refs.x;
-                leaf_top += (hl && refs.x < 0) ? CPT_WAVE : 0;
-                *leaf_top = (uint32_t)refs.y;
-                leaf_top += (hr && refs.y < 0) ? CPT_WAVE : 0;
+                {   // (both entries in one LDS store: the first is the left child if that is to be parked, else the right one)
+                    const bool park_l = hl && refs.x < 0, park_r = hr && refs.y < 0;
+                    leaf_top[0] = (uint32_t)(park_l ? refs.x : refs.y);
+                    leaf_top[CPT_WAVE] = (uint32_t)refs.y;
+                    leaf_top += ((park_l ? CPT_WAVE : 0) + (park_r ? CPT_WAVE : 0));
+                }
                 bool tl = hl && refs.x >= 0, tr = hr && refs.y >= 0;
                 if (LDS_STACK) {
                     if (tl) {
