@@ -456,6 +456,9 @@ __global__ void k_build_shade(const cpt_tri* __restrict__ tris, const cpt_tri_no
     r.inv_p_trans = 1 / r.inv_p_trans;
     double q = (1.0 - r.index) / (1.0 + r.index);
     r.r0 = q * q;
+    const dvec3 ca = dv(t.c) - dv(t.a);
+    r.ca[0] = ca.x; r.ca[1] = ca.y; r.ca[2] = ca.z;
+    r.denom = length(cross(dv(t.b) - dv(t.a), ca));
     out[i] = r;
 }
 

@@ -280,8 +280,8 @@ __device__ __forceinline__ dvec3 shading_normal(const ShadeRec* tp, const dvec3&
     dvec3 a = dv(tp->a), b = dv(tp->b), c = dv(tp->c);
     dvec3 P = o + d * t;
     double alpha = length(cross(b - P, c - P));
-    double beta = length(cross(P - a, c - a));
-    double denom = length(cross(b - a, c - a));
+    double beta = length(cross(P - a, dv(tp->ca)));  // c - a and the denominator do not depend on the ray: from the record (k_build_shade)
+    double denom = tp->denom;
     alpha /= denom;
     beta /= denom;
     return normalize(alpha * dv(tp->na) + beta * dv(tp->nb) + (1 - alpha - beta) * dv(tp->nc));

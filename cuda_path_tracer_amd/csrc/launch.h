@@ -30,7 +30,8 @@ struct __attribute__((aligned(128))) ShadeRec {
     double pad1[2];
     double a[3], b[3], c[3];           // third line: vertices, smooth-shaded triangles only
     double log_kt[3];                  // log|kt|, so that kt^t is one exp() at a hit inside the medium
-    double pad2[4];
+    double ca[3];                      // c - a, and ...
+    double denom;                      // ... length(cross(b - a, c - a)): the ray-independent operands of the barycentric weights (src/gpu/GPUTrimesh.cuh:91-97)
     double na[3], nb[3], nc[3];        // fourth line: vertex normals
     double pad3[7];
 };
