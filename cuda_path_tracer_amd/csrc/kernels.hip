@@ -477,7 +477,8 @@ __global__ void __launch_bounds__(CPT_PW_THREADS) k_extend_pw(DScene sc, RayStre
     constexpr bool RESIDENT = MODE == 2, LDS_STACK = MODE >= 1;
     // SEL: the resident instance of the exact variants keeps its records in the layout described at
     // CPT_PW_RESIDENT_NODE_BYTES: every lane reads, per child and axis, the plane its ray meets first and the one it
-    // meets last (slab_selected), and the instance without culling trades half of its node stack for record space.
+    // meets last (slab_selected), and the instance without culling gives the node-stack entries such a low tree cannot need
+    // to the records.
     constexpr bool SEL = RESIDENT && !F32;
     const void* const node_recs = EYE ? (const void*)sc.nodes_eye : (const void*)sc.nodes_pw;
     const void* const tri_recs = EYE ? (const void*)sc.tris_eye : (const void*)sc.tris;
