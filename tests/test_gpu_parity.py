@@ -355,7 +355,8 @@ def test_render_extend_kernel_visit_sets_bit_exact(name, gpu_scene, oracle_scene
     extend kernel the renderer launches (its counting instance): the order-free hash over the canonical ids of every
     node whose box was tested equals the oracle's for the one-ray-per-thread kernel and for the persistent kernel's
     reference walk (variants 0 and 1), on camera rays, random rays, tie-prone rays (aimed at box corners, starting
-    on box planes) and axis-parallel rays; hit triangle and t bits likewise.  On one scene also bitmap against bitmap."""
+    on box planes), axis-parallel rays and rays leaving the scene's surfaces; hit triangle and t bits likewise.  On one
+    scene also bitmap against bitmap."""
     g = gpu_scene(name)
     orc = oracle_scenes(name)
     rng = np.random.default_rng(17)
@@ -367,10 +368,17 @@ def test_render_extend_kernel_visit_sets_bit_exact(name, gpu_scene, oracle_scene
     d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
     o2, d2 = _tie_prone_rays(orc, rng, n)
     o3, d3 = orc.camera_rays(64, 64)
-    o = np.concatenate([o1, o2, o3])
-    d = np.concatenate([d1, d2, d3])
+    # rays that leave the scene's own surfaces, as every ray after the first does: the random rays' hit points, pushed
+    # 1e-12 along a random direction (they start on, or within rounding of, planes of the boxes around the triangle they left)
+    first = orc.trace(o1, d1)
+    hit = first["prim"] >= 0
+    d4 = rng.normal(size=(int(hit.sum()), 3))
+    d4 /= np.linalg.norm(d4, axis=1, keepdims=True)
+    o4 = o1[hit] + d1[hit] * first["t"][hit][:, None] + d4 * 1e-12
+    o = np.concatenate([o1, o2, o3, o4])
+    d = np.concatenate([d1, d2, d3, d4])
     want = orc.trace(o, d, bitmap=(name == "teapot-trans"))
-    assert len(np.unique(want["vhash"])) > 100
+    assert len(np.unique(want["vhash"])) > 100 and len(o4) > 500
     try:
         for variant in (1, 0):
             g.set_option("extend_variant", variant)
